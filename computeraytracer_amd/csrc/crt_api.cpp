@@ -1,0 +1,663 @@
+// crt_api.cpp -- the C ABI of include/crt.h on top of the gfx950 kernels.
+//
+// Host-side responsibilities (the reference does these in src/main.js):
+//   upload   main.js:147-393  -> crt_upload_scene (80-byte records -> device layout)
+//   state    main.js:298-311  -> accumulator + sample counter owned by the context
+//   dispatch main.js:597-611  -> crt_trace(n) == n x {sample++ ; trace}
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crt.h"
+#include "crt_bvh.h"
+#include "crt_device.h"
+#include "crt_math.h"
+
+namespace crt {
+hipError_t launch_trace(const TraceParams &P, bool count, bool brute, hipStream_t stream);
+hipError_t launch_debug_intersect(const DevScene &S, const float *rays, size_t n, float *out, int brute,
+                                  hipStream_t stream);
+hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
+}  // namespace crt
+
+using namespace crt;
+
+namespace {
+
+std::string g_create_error;
+
+// Host copy of one 80-byte record (ComputeShader.wgsl:41-47, main.js:211-246).
+struct HostPrim {
+    uint32_t category;
+    f3 d1, d2, d3;
+    uint32_t emission, reflectance, material, index;
+};
+
+HostPrim read_prim(const uint8_t *base, size_t i)
+{
+    HostPrim p;
+    const uint8_t *r = base + i * 80;
+    float f[9];
+    uint32_t u[4];
+    std::memcpy(&p.category, r, 4);
+    std::memcpy(f, r + 16, 12); std::memcpy(f + 3, r + 32, 12); std::memcpy(f + 6, r + 48, 12);
+    std::memcpy(u, r + 64, 16);
+    p.d1 = f3{f[0], f[1], f[2]}; p.d2 = f3{f[3], f[4], f[5]}; p.d3 = f3{f[6], f[7], f[8]};
+    p.emission = u[0]; p.reflectance = u[1]; p.material = u[2]; p.index = u[3];
+    return p;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct crt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // host copies
+    std::vector<HostPrim> prims;
+    std::vector<HostPrim> lights;
+    float camera[16] = {0};
+    uint32_t W = 0, H = 0;
+    bool have_scene = false;
+    int accel_mode = -1;            // -1: not built
+    Bvh bvh;
+
+    // device scene
+    DevBuf<float4> d_prim, d_primD, d_nodes, d_lights;
+    DevBuf<uint32_t> d_slot_of_index;
+    DevBuf<float> d_spectra, d_cie;
+    DevScene sc{};
+
+    // tile + outputs
+    uint32_t x0 = 0, y0 = 0, tw = 0, th = 0;
+    DevBuf<float4> d_accum;
+    DevBuf<uchar4> d_rgba;
+    float4 *accum_bound = nullptr;
+    uchar4 *rgba_bound = nullptr;
+    uint32_t sample = 0;
+
+    DevBuf<unsigned long long> d_counters;
+    bool counting = false;
+    float last_ms = 0.0f;
+    uint32_t last_launches = 0;
+    bool last_timed = false;
+    uint32_t spp_per_launch = 0;    // 0 = auto
+};
+
+namespace {
+
+int fail(crt_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(c, e_ == hipErrorOutOfMemory ? CRT_ENOMEM : CRT_EDEVICE, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                   \
+    } while (0)
+
+float4 *accum_ptr(crt_ctx *c) { return c->accum_bound ? c->accum_bound : c->d_accum.p; }
+uchar4 *rgba_ptr(crt_ctx *c) { return c->rgba_bound ? c->rgba_bound : c->d_rgba.p; }
+
+int alloc_tile(crt_ctx *c)
+{
+    size_t n = (size_t)c->tw * c->th;
+    HIPCHK(c, c->d_accum.alloc(n));
+    HIPCHK(c, c->d_rgba.alloc(n));
+    return CRT_OK;
+}
+
+int zero_state(crt_ctx *c)
+{
+    size_t n = (size_t)c->tw * c->th;
+    if (n) {
+        HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, n * sizeof(float4), c->stream));
+        HIPCHK(c, hipMemsetAsync(rgba_ptr(c), 0, n * sizeof(uchar4), c->stream));
+    }
+    c->sample = 0;
+    return CRT_OK;
+}
+
+// Primitive corners for bounds / scene scale (same op order as the oracle's orc_hit_pad).
+int prim_corners(const HostPrim &p, f3 out[4])
+{
+    if (p.category == 1u) {
+        float r = abs_(p.d2.x);
+        out[0] = f3{p.d1.x - r, p.d1.y - r, p.d1.z - r};
+        out[1] = f3{p.d1.x + r, p.d1.y + r, p.d1.z + r};
+        return 2;
+    }
+    out[0] = p.d1; out[1] = p.d1 + p.d2; out[2] = p.d1 + p.d3;
+    if (p.category == 0u) { out[3] = out[1] + p.d3; return 4; }
+    return 3;
+}
+
+float scene_hit_pad(const std::vector<HostPrim> &prims, const float cam[16])
+{
+    float S = 0.0f;
+    f3 c[4];
+    for (const HostPrim &p : prims) {
+        int nc = prim_corners(p, c);
+        for (int k = 0; k < nc; k++) {
+            S = max_(S, abs_(c[k].x)); S = max_(S, abs_(c[k].y)); S = max_(S, abs_(c[k].z));
+        }
+    }
+    S = max_(S, abs_(cam[0])); S = max_(S, abs_(cam[1])); S = max_(S, abs_(cam[2]));
+    return S * 7.62939453125e-06f;  // 2^-17
+}
+
+// ComputeShader.wgsl:470-487, everything independent of the pixel.
+void camera_frame(const float cam[16], float out[12])
+{
+    f3 eye = f3{cam[0], cam[1], cam[2]}, lookat = f3{cam[4], cam[5], cam[6]}, up = f3{cam[8], cam[9], cam[10]};
+    f3 w = normalize(eye - lookat);
+    f3 u = normalize(cross(up, w));
+    f3 v = cross(w, u);
+    float aspect_ratio = cam[11] / cam[12];
+    float viewport_height = 2.0f * tan_(cam[13] / 2.0f);
+    float viewport_width = aspect_ratio * viewport_height;
+    f3 horizontal = u * viewport_width;
+    f3 vertical = v * viewport_height;
+    f3 llc = ((eye - horizontal / 2.0f) - vertical / 2.0f) - w;
+    out[0] = llc.x; out[1] = llc.y; out[2] = llc.z;
+    out[3] = horizontal.x; out[4] = horizontal.y; out[5] = horizontal.z;
+    out[6] = vertical.x; out[7] = vertical.y; out[8] = vertical.z;
+    out[9] = eye.x; out[10] = eye.y; out[11] = eye.z;
+}
+
+// Builds the device primitive arrays in `order` and (for BVH2) the node array.
+int upload_geometry(crt_ctx *c, int mode)
+{
+    const uint32_t n = (uint32_t)c->prims.size();
+    const float pad = c->sc.hit_pad;
+    std::vector<uint32_t> order;
+    c->bvh = Bvh();
+    if (mode == CRT_ACCEL_BVH2 && n > 0) {
+        // Conservative boxes: the triangle acceptance box is [corner min - pad, corner max + pad];
+        // node boxes get 2*pad (covers the slab arithmetic), spheres an extra radial term.
+        float S = pad * 131072.0f;
+        std::vector<float> lo((size_t)n * 3), hi((size_t)n * 3);
+        f3 cs[4];
+        for (uint32_t i = 0; i < n; i++) {
+            const HostPrim &p = c->prims[i];
+            int nc = prim_corners(p, cs);
+            float l[3] = {cs[0].x, cs[0].y, cs[0].z}, h[3] = {cs[0].x, cs[0].y, cs[0].z};
+            for (int k = 1; k < nc; k++) {
+                l[0] = std::min(l[0], cs[k].x); l[1] = std::min(l[1], cs[k].y); l[2] = std::min(l[2], cs[k].z);
+                h[0] = std::max(h[0], cs[k].x); h[1] = std::max(h[1], cs[k].y); h[2] = std::max(h[2], cs[k].z);
+            }
+            float g = 2.0f * pad;
+            if (p.category == 0u) {
+                // The patch test accepts {P0+m : 0<=m.e1<=e1.e1, 0<=m.e2<=e2.e2} (ComputeShader.wgsl
+                // :563-566 use projections, which only equals the corner parallelogram when e1 is
+                // perpendicular to e2 -- cornell's box faces are not).  Bound THAT region.
+                double e1[3] = {p.d2.x, p.d2.y, p.d2.z}, e2[3] = {p.d3.x, p.d3.y, p.d3.z};
+                double g11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+                double g22 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+                double g12 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+                double det = g11 * g22 - g12 * g12;
+                if (!(det > 1e-9 * g11 * g22)) {
+                    l[0] = l[1] = l[2] = -3.0e38f; h[0] = h[1] = h[2] = 3.0e38f;   // unbounded strip
+                } else {
+                    double P0[3] = {p.d1.x, p.d1.y, p.d1.z};
+                    for (int k = 0; k < 4; k++) {
+                        double a = (k & 1) ? g11 : 0.0, b = (k & 2) ? g22 : 0.0;
+                        double al = (a * g22 - b * g12) / det, be = (b * g11 - a * g12) / det;
+                        for (int ax = 0; ax < 3; ax++) {
+                            double v = P0[ax] + al * e1[ax] + be * e2[ax];
+                            l[ax] = std::min(l[ax], (float)std::nextafter((float)v, -INFINITY));
+                            h[ax] = std::max(h[ax], (float)std::nextafter((float)v, INFINITY));
+                        }
+                    }
+                }
+            }
+            if (p.category == 1u) {
+                float r = std::fabs(p.d2.x);
+                g += (r > 0.0f) ? std::min(S * S * 9.5367431640625e-07f / r, S) : S;
+            }
+            for (int a = 0; a < 3; a++) {
+                if (!(l[a] == l[a]) || !(h[a] == h[a]) || std::isinf(l[a]) || std::isinf(h[a])) {
+                    l[a] = -3.0e38f; h[a] = 3.0e38f;      // non-finite primitive: never culled
+                }
+                lo[3 * i + a] = l[a] - g; hi[3 * i + a] = h[a] + g;
+            }
+        }
+        build_bvh2(lo.data(), hi.data(), n, c->bvh);
+        order = c->bvh.order;
+    } else {
+        order.resize(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        c->bvh.root = -1;
+    }
+
+    std::vector<float4> hp((size_t)n * 3), hd(n);
+    std::vector<uint32_t> slot_of(n);
+    for (uint32_t slot = 0; slot < n; slot++) {
+        const HostPrim &p = c->prims[order[slot]];
+        slot_of[p.index] = slot;
+        uint32_t meta = (p.category & 3u) | ((p.material & 3u) << 2) | ((p.emission & 0x3FFFu) << 4) |
+                        ((p.reflectance & 0x3FFFu) << 18);
+        float4 A = {p.d1.x, p.d1.y, p.d1.z, bits_f(meta)};
+        float4 B = {p.d2.x, p.d2.y, p.d2.z, bits_f(p.index)};
+        float4 C = {p.d3.x, p.d3.y, p.d3.z, 0.0f};
+        float4 D = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.category == 0u) {
+            f3 nrm = normalize(cross(p.d2, p.d3));               // ComputeShader.wgsl:536
+            D = float4{nrm.x, nrm.y, nrm.z, dot(p.d2, p.d2)};    // :563 denominator
+            C.w = dot(p.d3, p.d3);                               // :564 denominator
+        } else if (p.category == 1u) {
+            float r = p.d2.x;                                    // :593-594
+            B = float4{r, r * r, 0.0f, bits_f(p.index)};
+        }
+        hp[3 * (size_t)slot + 0] = A; hp[3 * (size_t)slot + 1] = B; hp[3 * (size_t)slot + 2] = C;
+        hd[slot] = D;
+    }
+    HIPCHK(c, c->d_prim.alloc(std::max<size_t>(hp.size(), 3)));
+    HIPCHK(c, c->d_primD.alloc(std::max<size_t>(hd.size(), 1)));
+    HIPCHK(c, c->d_slot_of_index.alloc(std::max<size_t>(n, 1)));
+    if (n) {
+        HIPCHK(c, hipMemcpy(c->d_prim.p, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_primD.p, hd.data(), hd.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_slot_of_index.p, slot_of.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    size_t nn = c->bvh.nodes.size() / 4;
+    HIPCHK(c, c->d_nodes.alloc(std::max<size_t>(nn, 4)));
+    if (nn) HIPCHK(c, hipMemcpy(c->d_nodes.p, c->bvh.nodes.data(), nn * sizeof(float4), hipMemcpyHostToDevice));
+    c->sc.prim = c->d_prim.p;
+    c->sc.primD = c->d_primD.p;
+    c->sc.slot_of_index = c->d_slot_of_index.p;
+    c->sc.nodes = c->d_nodes.p;
+    c->sc.root = c->bvh.root;
+    c->sc.nprim = n;
+    c->accel_mode = mode;
+    return CRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crt_abi_version(void) { return CRT_ABI_VERSION; }
+
+const char *crt_last_error(crt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int crt_create(crt_ctx **out, int device_ordinal)
+{
+    if (!out) return fail(nullptr, CRT_EINVAL, "crt_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CRT_EDEVICE, "crt_create: no HIP device (%s); there is no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_ordinal < 0 || device_ordinal >= ndev)
+        return fail(nullptr, CRT_EINVAL, "crt_create: device %d out of range (0..%d)", device_ordinal, ndev - 1);
+    crt_ctx *c = new crt_ctx();
+    c->device = device_ordinal;
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = c->d_counters.alloc(CRT_NCOUNTERS)) != hipSuccess ||
+        (e = hipMemset(c->d_counters.p, 0, CRT_NCOUNTERS * sizeof(unsigned long long))) != hipSuccess) {
+        int rc = fail(nullptr, CRT_EDEVICE, "crt_create: %s", hipGetErrorString(e));
+        crt_destroy(c);
+        return rc;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return CRT_OK;
+}
+
+void crt_destroy(crt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_lights.release();
+    c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
+    c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const void *lights, size_t nlight,
+                     const float *spectra, size_t nspectra, const float *cie, const float camera[16])
+{
+    if (!c) return CRT_EINVAL;
+    if ((!primitives && nprim) || !lights || !spectra || !cie || !camera)
+        return fail(c, CRT_EINVAL, "crt_upload_scene: NULL buffer");
+    if (nlight < 1) return fail(c, CRT_EINVAL, "crt_upload_scene: at least one light record is required");
+    if (nspectra < 1 || nspectra > 0x3FFF) return fail(c, CRT_EINVAL, "crt_upload_scene: nspectra must be 1..16383");
+    if (nprim >= (1u << 28)) return fail(c, CRT_EINVAL, "crt_upload_scene: too many primitives");
+    if (!(camera[11] >= 1.0f && camera[12] >= 1.0f && camera[11] <= 65536.0f && camera[12] <= 65536.0f))
+        return fail(c, CRT_EINVAL, "crt_upload_scene: camera width/height (floats 11,12) must be 1..65536");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    std::vector<HostPrim> prims(nprim), lts(nlight);
+    for (size_t i = 0; i < nprim; i++) {
+        prims[i] = read_prim((const uint8_t *)primitives, i);
+        const HostPrim &p = prims[i];
+        if (p.category > 2u) return fail(c, CRT_EINVAL, "primitive %zu: category %u not in {0,1,2}", i, p.category);
+        if (p.material > 2u) return fail(c, CRT_EINVAL, "primitive %zu: material %u not in {0,1,2}", i, p.material);
+        if (p.index != (uint32_t)i)
+            return fail(c, CRT_EINVAL, "primitive %zu: data4.w (index) is %u, must equal the array position "
+                                       "(src/main.js:124,133)", i, p.index);
+        if (p.emission >= nspectra || p.reflectance >= nspectra)
+            return fail(c, CRT_EINVAL, "primitive %zu: spectrum index out of range", i);
+    }
+    for (size_t i = 0; i < nlight; i++) {
+        lts[i] = read_prim((const uint8_t *)lights, i);
+        if (lts[i].emission >= nspectra) return fail(c, CRT_EINVAL, "light %zu: emission index out of range", i);
+    }
+    c->prims.swap(prims);
+    c->lights.swap(lts);
+    std::memcpy(c->camera, camera, sizeof c->camera);
+    c->W = (uint32_t)camera[11];                                 // ComputeShader.wgsl:85
+    c->H = (uint32_t)camera[12];
+
+    DevScene &S = c->sc;
+    S = DevScene{};
+    S.W = c->W; S.H = c->H;
+    S.nspectra = (uint32_t)nspectra;
+    S.nlight = (uint32_t)nlight;
+    S.inv_nlight = 1.0f / (float)S.nlight;                       // :372-373
+    S.hit_pad = scene_hit_pad(c->prims, c->camera);
+    camera_frame(c->camera, S.cam);
+
+    HIPCHK(c, c->d_spectra.alloc(nspectra * kNLambda));
+    HIPCHK(c, hipMemcpy(c->d_spectra.p, spectra, nspectra * kNLambda * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, c->d_cie.alloc(3 * kNCie));
+    HIPCHK(c, hipMemcpy(c->d_cie.p, cie, 3 * kNCie * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float4> hl(nlight * 3);
+    for (size_t i = 0; i < nlight; i++) {
+        const HostPrim &l = c->lights[i];
+        float light_area = length(l.d2) * length(l.d3);          // :363
+        hl[3 * i + 0] = float4{l.d1.x, l.d1.y, l.d1.z, bits_f(l.emission)};
+        hl[3 * i + 1] = float4{l.d2.x, l.d2.y, l.d2.z, bits_f(l.index)};
+        hl[3 * i + 2] = float4{l.d3.x, l.d3.y, l.d3.z, 1.0f / light_area};   // :364
+    }
+    HIPCHK(c, c->d_lights.alloc(hl.size()));
+    HIPCHK(c, hipMemcpy(c->d_lights.p, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
+    S.spectra = c->d_spectra.p; S.cie = c->d_cie.p; S.lights = c->d_lights.p;
+
+    c->have_scene = true;
+    c->accel_mode = -1;
+    c->x0 = 0; c->y0 = 0; c->tw = c->W; c->th = c->H;
+    c->accum_bound = nullptr; c->rgba_bound = nullptr;
+    int rc = alloc_tile(c);
+    if (rc) return rc;
+    return zero_state(c);
+}
+
+int crt_set_tile(crt_ctx *c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_set_tile: upload a scene first");
+    if (x0 > x1 || y0 > y1 || x1 > c->W || y1 > c->H)
+        return fail(c, CRT_EINVAL, "crt_set_tile: rectangle [%u,%u)x[%u,%u) outside %ux%u", x0, x1, y0, y1, c->W, c->H);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->x0 = x0; c->y0 = y0; c->tw = x1 - x0; c->th = y1 - y0;
+    c->accum_bound = nullptr; c->rgba_bound = nullptr;
+    int rc = alloc_tile(c);
+    if (rc) return rc;
+    return zero_state(c);
+}
+
+int crt_build_accel(crt_ctx *c, int mode)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_build_accel: upload a scene first");
+    if (mode != CRT_ACCEL_NONE && mode != CRT_ACCEL_BVH2) return fail(c, CRT_EINVAL, "crt_build_accel: unknown mode %d", mode);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return upload_geometry(c, mode);
+}
+
+int crt_reset(crt_ctx *c)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_reset: upload a scene first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return zero_state(c);
+}
+
+int crt_trace(crt_ctx *c, uint32_t n_samples)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_trace: upload a scene first");
+    if (c->accel_mode < 0) return fail(c, CRT_ESTATE, "crt_trace: call crt_build_accel first");
+    HIPCHK(c, hipSetDevice(c->device));
+    TraceParams P{};
+    P.sc = c->sc;
+    P.x0 = c->x0; P.y0 = c->y0; P.tw = c->tw; P.th = c->th;
+    P.accum = accum_ptr(c); P.rgba = rgba_ptr(c);
+    P.counters = c->counting ? c->d_counters.p : nullptr;
+    P.tiles_x = (c->tw + 7) / 8; P.tiles_y = (c->th + 7) / 8;        // main.js:606-610
+    uint32_t chunk = c->spp_per_launch ? c->spp_per_launch : 8u;
+    c->last_launches = 0;
+    c->last_timed = true;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    uint32_t left = n_samples;
+    while (left) {
+        uint32_t n = std::min(left, chunk);
+        P.first_sample = c->sample + 1;                               // UpdateVariables.wgsl: sample++ first
+        P.n_samples = n;
+        HIPCHK(c, launch_trace(P, c->counting, c->accel_mode == CRT_ACCEL_NONE, c->stream));
+        c->sample += n;
+        left -= n;
+        c->last_launches++;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    return CRT_OK;
+}
+
+int crt_sync(crt_ctx *c)
+{
+    if (!c) return CRT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_sample_count(crt_ctx *c, uint32_t *out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    *out = c->sample;
+    return CRT_OK;
+}
+
+int crt_tile(crt_ctx *c, uint32_t out[4])
+{
+    if (!c || !out) return CRT_EINVAL;
+    out[0] = c->x0; out[1] = c->y0; out[2] = c->tw; out[3] = c->th;
+    return CRT_OK;
+}
+
+int crt_read_accum(crt_ctx *c, float *out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_accum: no scene");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->tw * c->th;
+    if (n) HIPCHK(c, hipMemcpyAsync(out, accum_ptr(c), n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_read_rgba8(crt_ctx *c, uint8_t *out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_rgba8: no scene");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->tw * c->th;
+    if (n) HIPCHK(c, hipMemcpyAsync(out, rgba_ptr(c), n * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
+{
+    if (!c || !in) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_write_accum: no scene");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t n = (size_t)c->tw * c->th;
+    if (n) HIPCHK(c, hipMemcpyAsync(accum_ptr(c), in, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sample = sample;
+    return CRT_OK;
+}
+
+int crt_device_buffers(crt_ctx *c, void **accum_dev, void **rgba8_dev)
+{
+    if (!c) return CRT_EINVAL;
+    if (accum_dev) *accum_dev = accum_ptr(c);
+    if (rgba8_dev) *rgba8_dev = rgba_ptr(c);
+    return CRT_OK;
+}
+
+int crt_bind_output(crt_ctx *c, void *accum_dev, void *rgba8_dev)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_bind_output: upload a scene first");
+    if (((uintptr_t)accum_dev & 15u) || ((uintptr_t)rgba8_dev & 3u))
+        return fail(c, CRT_EINVAL, "crt_bind_output: accum must be 16-byte and rgba8 4-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->accum_bound = (float4 *)accum_dev;
+    c->rgba_bound = (uchar4 *)rgba8_dev;
+    return CRT_OK;
+}
+
+int crt_set_stream(crt_ctx *c, void *hip_stream)
+{
+    if (!c) return CRT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return CRT_OK;
+}
+
+int crt_enable_counters(crt_ctx *c, int on)
+{
+    if (!c) return CRT_EINVAL;
+    c->counting = on != 0;
+    return CRT_OK;
+}
+
+int crt_reset_counters(crt_ctx *c)
+{
+    if (!c) return CRT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, CRT_NCOUNTERS * sizeof(unsigned long long), c->stream));
+    return CRT_OK;
+}
+
+int crt_counters(crt_ctx *c, uint64_t out[CRT_NCOUNTERS])
+{
+    if (!c || !out) return CRT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_counters.p, CRT_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_last_trace_ms(crt_ctx *c, float *ms, uint32_t *launches)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->last_timed) return fail(c, CRT_ESTATE, "crt_last_trace_ms: no crt_trace yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float t = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    c->last_ms = t;
+    if (ms) *ms = t;
+    if (launches) *launches = c->last_launches;
+    return CRT_OK;
+}
+
+int crt_accel_stats(crt_ctx *c, uint64_t out[4])
+{
+    if (!c || !out) return CRT_EINVAL;
+    out[0] = c->bvh.n_inner; out[1] = c->bvh.n_leaves; out[2] = c->bvh.max_depth;
+    out[3] = (uint64_t)c->bvh.n_inner * 64u + (uint64_t)c->prims.size() * 48u;
+    return CRT_OK;
+}
+
+int crt_set_option(crt_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return CRT_EINVAL;
+    if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
+    return fail(c, CRT_EINVAL, "crt_set_option: unknown option '%s'", name);
+}
+
+int crt_debug_intersect(crt_ctx *c, const float *rays, size_t n, float *out)
+{
+    if (!c || (!rays && n) || (!out && n)) return CRT_EINVAL;
+    if (!c->have_scene || c->accel_mode < 0) return fail(c, CRT_ESTATE, "crt_debug_intersect: scene + accel required");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf<float> din, dout;
+    HIPCHK(c, din.alloc(n * 8));
+    hipError_t e = dout.alloc(n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(din.p, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_debug_intersect(c->sc, din.p, n, dout.p, c->accel_mode == CRT_ACCEL_NONE, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, n * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    din.release(); dout.release();
+    if (e != hipSuccess) return fail(c, CRT_EDEVICE, "crt_debug_intersect: %s", hipGetErrorString(e));
+    return CRT_OK;
+}
+
+int crt_debug_math(crt_ctx *c, int fn, const float *a, const float *b, float *out, size_t n)
+{
+    if (!c || !a || !b || !out) return CRT_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf<float> da, db, dout;
+    hipError_t e = da.alloc(n);
+    if (e == hipSuccess) e = db.alloc(n);
+    if (e == hipSuccess) e = dout.alloc(n);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(da.p, a, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(db.p, b, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_debug_math(fn, da.p, db.p, dout.p, n, c->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    da.release(); db.release(); dout.release();
+    if (e != hipSuccess) return fail(c, CRT_EDEVICE, "crt_debug_math: %s", hipGetErrorString(e));
+    return CRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// crt_bvh.cpp -- binned-SAH BVH2 build on the host (multi-threaded over subtrees).
+#include "crt_bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace crt {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { lo[0] = lo[1] = lo[2] = FLT_MAX; hi[0] = hi[1] = hi[2] = -FLT_MAX; }
+    void grow(const float *l, const float *h) {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+    }
+    void grow(const Box &b) { grow(b.lo, b.hi); }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int kBins = 16;
+constexpr float kCostTrav = 1.2f;   // one inner visit (two boxes, 64 B) vs one primitive test
+constexpr float kCostIsect = 1.0f;
+
+struct Builder {
+    const float *lo, *hi;
+    uint32_t n;
+    std::vector<uint32_t> &order;
+    std::vector<float> cent;            // n x 3 centroids (of the boxes)
+    std::vector<float> &nodes;
+    std::atomic<uint32_t> next_node{0};
+    std::atomic<uint32_t> n_leaves{0};
+    std::atomic<uint32_t> max_depth{0};
+    std::atomic<int> threads_left;
+
+    Builder(const float *l, const float *h, uint32_t n_, std::vector<uint32_t> &ord, std::vector<float> &nd)
+        : lo(l), hi(h), n(n_), order(ord), nodes(nd), threads_left(0) {}
+
+    int32_t make_leaf(uint32_t begin, uint32_t count, uint32_t depth) {
+        n_leaves++;
+        uint32_t d = max_depth.load();
+        while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+        return ~(int32_t)((begin << 3) | (count - 1));
+    }
+
+    // Builds [begin,end) of `order`; returns the child reference and its bounds.
+    int32_t build(uint32_t begin, uint32_t end, uint32_t depth, Box &bounds) {
+        uint32_t count = end - begin;
+        bounds.reset();
+        Box cb; cb.reset();
+        for (uint32_t i = begin; i < end; i++) {
+            uint32_t p = order[i];
+            bounds.grow(lo + 3 * p, hi + 3 * p);
+            const float *c = &cent[3 * p];
+            cb.grow(c, c);
+        }
+        if (count == 1) return make_leaf(begin, 1, depth);
+
+        // Capacity that keeps every leaf at depth <= kMaxDepth.
+        int levels_left = kMaxDepth - (int)depth;          // levels available below this node
+        uint64_t child_cap = (levels_left >= 1) ? ((uint64_t)kMaxLeaf << std::min(levels_left - 1, 40)) : 0;
+
+        int best_axis = -1, best_bin = -1;
+        float best_cost = FLT_MAX;
+        float ext[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+        if (levels_left >= 1) {
+            for (int axis = 0; axis < 3; axis++) {
+                if (!(ext[axis] > 0.0f)) continue;
+                Box bb[kBins]; uint32_t bc[kBins];
+                for (int b = 0; b < kBins; b++) { bb[b].reset(); bc[b] = 0; }
+                float scale = (float)kBins / ext[axis];
+                for (uint32_t i = begin; i < end; i++) {
+                    uint32_t p = order[i];
+                    int b = (int)((cent[3 * p + axis] - cb.lo[axis]) * scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    bb[b].grow(lo + 3 * p, hi + 3 * p);
+                    bc[b]++;
+                }
+                float right_area[kBins]; uint32_t right_cnt[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; b--) {
+                    if (bc[b]) acc.grow(bb[b]);
+                    c += bc[b];
+                    right_area[b] = c ? acc.half_area() : 0.0f;
+                    right_cnt[b] = c;
+                }
+                acc.reset(); c = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    if (bc[b]) acc.grow(bb[b]);
+                    c += bc[b];
+                    uint32_t rc = right_cnt[b + 1];
+                    if (c == 0 || rc == 0) continue;
+                    if (c > child_cap || rc > child_cap) continue;
+                    float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)rc;
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+        }
+        float parent_area = bounds.half_area();
+        if (count <= (uint32_t)kMaxLeaf) {
+            float leaf_cost = kCostIsect * (float)count;
+            float split_cost = (best_axis >= 0 && parent_area > 0.0f)
+                                   ? kCostTrav + kCostIsect * best_cost / parent_area : FLT_MAX;
+            if (!(split_cost < leaf_cost) || levels_left < 1) return make_leaf(begin, count, depth);
+        }
+        uint32_t mid;
+        if (best_axis >= 0) {
+            float scale = (float)kBins / ext[best_axis];
+            float clo = cb.lo[best_axis];
+            int axis = best_axis, bin = best_bin;
+            auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t p) {
+                int b = (int)((cent[3 * p + axis] - clo) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                return b <= bin;
+            });
+            mid = (uint32_t)(it - order.begin());
+        } else {
+            // degenerate centroids or no admissible SAH split: object median on the widest axis
+            int axis = 0;
+            if (ext[1] > ext[axis]) axis = 1;
+            if (ext[2] > ext[axis]) axis = 2;
+            mid = begin + count / 2;
+            std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+                             [&](uint32_t a, uint32_t b) {
+                                 float ca = cent[3 * a + axis], cb2 = cent[3 * b + axis];
+                                 return ca < cb2 || (ca == cb2 && a < b);
+                             });
+        }
+        if (mid == begin || mid == end) mid = begin + count / 2;
+
+        uint32_t node = next_node.fetch_add(1);
+        Box b0, b1;
+        int32_t r0, r1;
+        bool spawn = count > 200000 && threads_left.fetch_sub(1) > 0;
+        if (spawn) {
+            std::thread t([&] { r0 = build(begin, mid, depth + 1, b0); });
+            r1 = build(mid, end, depth + 1, b1);
+            t.join();
+            threads_left.fetch_add(1);
+        } else {
+            if (count > 200000) threads_left.fetch_add(1);
+            r0 = build(begin, mid, depth + 1, b0);
+            r1 = build(mid, end, depth + 1, b1);
+        }
+        float *nd = &nodes[(size_t)node * kNodeFloats];
+        for (int a = 0; a < 3; a++) {
+            nd[a] = b0.lo[a]; nd[3 + a] = b0.hi[a];
+            nd[6 + a] = b1.lo[a]; nd[9 + a] = b1.hi[a];
+        }
+        std::memcpy(&nd[12], &r0, 4);
+        std::memcpy(&nd[13], &r1, 4);
+        nd[14] = 0.0f; nd[15] = 0.0f;
+        return (int32_t)node;
+    }
+};
+
+}  // namespace
+
+void build_bvh2(const float *lo, const float *hi, uint32_t n, Bvh &out)
+{
+    out = Bvh();
+    out.order.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.order[i] = i;
+    if (n == 0) { out.root = -1; return; }
+    out.nodes.assign((size_t)std::max<uint32_t>(n, 1) * kNodeFloats, 0.0f);
+    Builder b(lo, hi, n, out.order, out.nodes);
+    b.cent.resize((size_t)n * 3);
+    for (size_t i = 0; i < (size_t)n * 3; i++) b.cent[i] = 0.5f * lo[i] + 0.5f * hi[i];
+    unsigned hw = std::thread::hardware_concurrency();
+    b.threads_left = (int)std::min<unsigned>(hw ? hw : 1, 32) - 1;
+    Box root_bounds;
+    out.root = b.build(0, n, 0, root_bounds);
+    out.n_inner = b.next_node.load();
+    out.n_leaves = b.n_leaves.load();
+    out.max_depth = b.max_depth.load();
+    out.nodes.resize((size_t)std::max<uint32_t>(out.n_inner, 1) * kNodeFloats);
+}
+
+}  // namespace crt

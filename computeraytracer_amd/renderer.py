@@ -1,0 +1,190 @@
+"""Host driver over the C ABI: the Python counterpart of the reference's
+``Main()`` / ``frame()`` (src/main.js:7-624) minus the browser.
+
+    Main():  requestDevice                -> Renderer(device)
+             createBuffer(b4..b8) + unmap -> Renderer.upload(PackedScene)
+             accumulator + sample = 0     -> (done by upload / reset)
+    frame(): dispatch(1); dispatch(W/8,H/8) -> Renderer.frame(n)   (n frames fused)
+    (the reference never reads back; read_accum/read_rgba8 replace its blit pass)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ACCEL_BVH2, ACCEL_NONE, CNT, CrtError, NCOUNTERS
+from .scene import PackedScene
+
+_ACCEL = {"none": ACCEL_NONE, "brute": ACCEL_NONE, "bvh2": ACCEL_BVH2, "bvh": ACCEL_BVH2,
+          ACCEL_NONE: ACCEL_NONE, ACCEL_BVH2: ACCEL_BVH2}
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.crt_create(C.byref(h), int(device))
+        if rc != 0:
+            raise CrtError(rc, (self._lib.crt_last_error(None) or b"").decode())
+        self._h = h
+        self.device = int(device)
+        self.scene: PackedScene | None = None
+
+    # -- plumbing
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise CrtError(rc, (self._lib.crt_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.crt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- Main()
+    def upload(self, ps: PackedScene):
+        prim = np.ascontiguousarray(ps.primitives)
+        lights = np.ascontiguousarray(ps.lights)
+        spectra = np.ascontiguousarray(ps.spectra, np.float32)
+        cie = np.ascontiguousarray(ps.cie, np.float32)
+        cam = np.ascontiguousarray(ps.camera, np.float32)
+        if prim.nbytes % 80 or lights.nbytes % 80:
+            raise ValueError("primitive / light buffers must be multiples of 80 bytes")
+        if spectra.size % 301 or cie.size != 3 * 471 or cam.size != 16:
+            raise ValueError("spectra must be n x 301, cie 3 x 471, camera 16 floats")
+        self._chk(self._lib.crt_upload_scene(self._h, prim.ctypes.data, prim.nbytes // 80,
+                                             lights.ctypes.data, lights.nbytes // 80,
+                                             spectra.ctypes.data, spectra.size // 301,
+                                             cie.ctypes.data, cam.ctypes.data))
+        self.scene = ps
+        return self
+
+    def set_tile(self, x0: int, y0: int, x1: int, y1: int):
+        self._chk(self._lib.crt_set_tile(self._h, x0, y0, x1, y1))
+        return self
+
+    def build_accel(self, mode="bvh2"):
+        self._chk(self._lib.crt_build_accel(self._h, _ACCEL[mode]))
+        return self
+
+    def reset(self):
+        self._chk(self._lib.crt_reset(self._h))
+        return self
+
+    def set_option(self, name: str, value: int):
+        self._chk(self._lib.crt_set_option(self._h, name.encode(), int(value)))
+        return self
+
+    # -- frame()
+    def frame(self, n_samples: int = 1):
+        """n x { sample++ ; trace }  (asynchronous)."""
+        self._chk(self._lib.crt_trace(self._h, int(n_samples)))
+        return self
+
+    def sync(self):
+        self._chk(self._lib.crt_sync(self._h))
+        return self
+
+    @property
+    def sample(self) -> int:
+        v = C.c_uint32()
+        self._chk(self._lib.crt_sample_count(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def tile(self):
+        out = (C.c_uint32 * 4)()
+        self._chk(self._lib.crt_tile(self._h, out))
+        return tuple(out)
+
+    # -- readback
+    def read_accum(self) -> np.ndarray:
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.float32)
+        self._chk(self._lib.crt_read_accum(self._h, out.ctypes.data))
+        return out
+
+    def read_rgba8(self) -> np.ndarray:
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.uint8)
+        self._chk(self._lib.crt_read_rgba8(self._h, out.ctypes.data))
+        return out
+
+    def write_accum(self, accum: np.ndarray, sample: int):
+        a = np.ascontiguousarray(accum, np.float32)
+        _, _, tw, th = self.tile
+        if a.size != tw * th * 4:
+            raise ValueError("accum must be th x tw x 4 float32")
+        self._chk(self._lib.crt_write_accum(self._h, a.ctypes.data, int(sample)))
+        return self
+
+    def device_buffers(self):
+        a, r = C.c_void_p(), C.c_void_p()
+        self._chk(self._lib.crt_device_buffers(self._h, C.byref(a), C.byref(r)))
+        return a.value, r.value
+
+    def bind_output(self, accum_dev_ptr: int | None, rgba_dev_ptr: int | None):
+        self._chk(self._lib.crt_bind_output(self._h, C.c_void_p(accum_dev_ptr or 0), C.c_void_p(rgba_dev_ptr or 0)))
+        return self
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self._lib.crt_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        return self
+
+    # -- measurement
+    def enable_counters(self, on: bool = True):
+        self._chk(self._lib.crt_enable_counters(self._h, 1 if on else 0))
+        return self
+
+    def reset_counters(self):
+        self._chk(self._lib.crt_reset_counters(self._h))
+        return self
+
+    def counters(self) -> dict:
+        out = np.zeros(NCOUNTERS, np.uint64)
+        self._chk(self._lib.crt_counters(self._h, out.ctypes.data))
+        return {k: int(out[i]) for k, i in CNT.items()}
+
+    def last_trace_ms(self):
+        ms, n = C.c_float(), C.c_uint32()
+        self._chk(self._lib.crt_last_trace_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def accel_stats(self) -> dict:
+        out = np.zeros(4, np.uint64)
+        self._chk(self._lib.crt_accel_stats(self._h, out.ctypes.data))
+        return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), bytes=int(out[3]))
+
+    # -- test hooks
+    def debug_intersect(self, origins, directions, exclude=None) -> np.ndarray:
+        o = np.asarray(origins, np.float32).reshape(-1, 3)
+        d = np.asarray(directions, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        rays = np.zeros((n, 8), np.float32)
+        rays[:, 0:3] = o
+        rays[:, 3:6] = d
+        ex = np.full(n, 0xFFFFFFFF, np.uint32) if exclude is None else np.asarray(exclude, np.uint32)
+        rays[:, 6] = ex.view(np.float32)
+        out = np.zeros((n, 8), np.float32)
+        self._chk(self._lib.crt_debug_intersect(self._h, rays.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def debug_math(self, fn: int, a, b=None) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), np.float32)
+        out = np.empty_like(a)
+        self._chk(self._lib.crt_debug_math(self._h, int(fn), a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
+        return out

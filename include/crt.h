@@ -1,0 +1,155 @@
+/*
+ * crt.h -- C ABI of libcrt.so, the MI355X (gfx950) drop-in for the reference's
+ * WebGPU path-trace compute pass.
+ *
+ * What it replaces (all paths under Meryx/ComputeRayTracer):
+ *   - the device side:  src/shaders/ComputeShader.wgsl:77-117 (`main`) and
+ *     src/shaders/UpdateVariables.wgsl:1-7 (`sample++`);
+ *   - the host calls that feed and drive it in src/main.js:
+ *       createBuffer/getMappedRange/unmap of bind-group-0 entries b4..b8
+ *                                   (main.js:147-155,249-253,263-296,313-393)
+ *       the zeroed accumulator + sample counter           (main.js:298-311)
+ *       per-frame  dispatchWorkgroups(1) ; dispatchWorkgroups(ceil(W/8),ceil(H/8))
+ *                                                          (main.js:598-611)
+ *       uncapturederror reporting                          (main.js:11-14)
+ *
+ * Conventions: plain C, caller-owned host pointers, sizes in records unless
+ * stated; every function returns 0 on success or a negative CRT_E* code and
+ * leaves a message for crt_last_error().  One thread per context.  Work is
+ * enqueued on the context's HIP stream; crt_sync / crt_read_* wait for it.
+ * There is NO CPU fallback: without a HIP device crt_create fails.
+ */
+#ifndef CRT_H
+#define CRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+enum {
+    CRT_OK = 0,
+    CRT_EINVAL = -1,   /* bad argument / malformed buffer            */
+    CRT_EDEVICE = -2,  /* HIP runtime error (message has the detail) */
+    CRT_ESTATE = -3,   /* call out of order (e.g. trace before upload) */
+    CRT_ENOMEM = -4
+};
+
+/* Acceleration modes for crt_build_accel. */
+enum {
+    CRT_ACCEL_NONE = 0, /* the reference's own loop over every primitive
+                           (ComputeShader.wgsl:503-518), on the GPU        */
+    CRT_ACCEL_BVH2 = 1  /* binned-SAH BVH2; returns exactly what the loop
+                           returns (closest t; equal t -> later primitive) */
+};
+
+/* Counter slots for crt_counters(). */
+enum {
+    CRT_CNT_RAYS = 0,        /* intersect() invocations (primary+bounce+shadow) */
+    CRT_CNT_NODES = 1,       /* BVH child boxes tested (2 per inner-node visit) */
+    CRT_CNT_PRIMS = 2,       /* primitive intersection tests                    */
+    CRT_CNT_PATHS = 3,       /* pixel-samples                                   */
+    CRT_CNT_BOUNCES = 4,     /* path-loop iterations                            */
+    CRT_CNT_SHADOW = 5,      /* shadow rays (subset of RAYS)                    */
+    CRT_CNT_HITS = 6,        /* closest-hit attribute fetches                   */
+    CRT_CNT_RESERVED = 7,
+    CRT_NCOUNTERS = 8
+};
+
+typedef struct crt_ctx crt_ctx;
+
+/* ~ navigator.gpu.requestAdapter()/requestDevice(), main.js:8-9. */
+int crt_create(crt_ctx **out, int device_ordinal);
+void crt_destroy(crt_ctx *ctx);
+const char *crt_last_error(crt_ctx *ctx);   /* ctx may be NULL: last create error */
+int crt_abi_version(void);
+
+/* ~ the b4..b8 buffer uploads (main.js:147-393).  Byte layouts are exactly the
+ * reference's: 80-byte Primitive records (category@0, data1@16, data2@32,
+ * data3@48, data4@64 = emission_idx, reflectance_idx, material, index), camera
+ * = 16 floats (eye,_,lookat,_,up,width,height,focal,_,_), spectra = nspectra
+ * rows of 301 floats (last row = glass extinction), cie = 3 x 471 floats.
+ * Requirements checked here: data4.w == array position (main.js:124,133
+ * guarantees it), category in {0 patch,1 sphere,2 triangle}, material in
+ * {0,1,2}, nlight >= 1.  Resets the accumulator and the accel structure. */
+int crt_upload_scene(crt_ctx *ctx,
+                     const void *primitives, size_t nprim,
+                     const void *lights, size_t nlight,
+                     const float *spectra, size_t nspectra,
+                     const float *cie,
+                     const float camera[16]);
+
+/* Restrict this context to the pixel rectangle [x0,x1) x [y0,y1) of the full
+ * W x H image (image-tile partition across GPUs).  Default: the whole image.
+ * RNG seeds use the GLOBAL pixel coordinates (ComputeShader.wgsl:98), so a
+ * tile is bit-identical to the same pixels of a full-frame render.  Resets the
+ * accumulator. */
+int crt_set_tile(crt_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+
+int crt_build_accel(crt_ctx *ctx, int mode);
+
+/* ~ main.js:298-311: zero alt_color_buffer, sample = 0. */
+int crt_reset(crt_ctx *ctx);
+
+/* ~ n_samples iterations of frame() (main.js:597-611):
+ *   { sample++ (UpdateVariables.wgsl) ; path-trace dispatch (ComputeShader.wgsl) }.
+ * Samples are accumulated into alt_color_buffer in order; the rgba8
+ * framebuffer holds the tone-mapped average after the last one. Asynchronous. */
+int crt_trace(crt_ctx *ctx, uint32_t n_samples);
+int crt_sync(crt_ctx *ctx);
+
+/* Current value of the `sample` counter (ComputeShader.wgsl:3). */
+int crt_sample_count(crt_ctx *ctx, uint32_t *out);
+
+/* Tile geometry: out[4] = x0, y0, width, height. */
+int crt_tile(crt_ctx *ctx, uint32_t out[4]);
+
+/* Readback of this context's tile, row-major, row 0 = top (the reference never
+ * reads back; its blit pass is display-only).  accum: tw*th*4 floats (x,y,z,
+ * pad -- the 16-byte stride of array<vec3<f32>>); rgba8: tw*th*4 bytes. */
+int crt_read_accum(crt_ctx *ctx, float *out);
+int crt_read_rgba8(crt_ctx *ctx, uint8_t *out);
+/* Restore an accumulator + sample count (checkpoint/resume). */
+int crt_write_accum(crt_ctx *ctx, const float *in, uint32_t sample);
+
+/* Device pointers of the tile buffers (for an RCCL gather by the caller). */
+int crt_device_buffers(crt_ctx *ctx, void **accum_dev, void **rgba8_dev);
+/* Render into caller-owned DEVICE memory instead (e.g. a slice of a gather
+ * buffer): accum_dev >= tw*th*16 B, rgba8_dev >= tw*th*4 B; NULL restores the
+ * internal buffers. */
+int crt_bind_output(crt_ctx *ctx, void *accum_dev, void *rgba8_dev);
+/* Enqueue on the caller's hipStream_t instead of the context's own. */
+int crt_set_stream(crt_ctx *ctx, void *hip_stream);
+
+/* Counters accumulate over crt_trace calls while enabled (off by default: the
+ * counting kernel variant is slower). */
+int crt_enable_counters(crt_ctx *ctx, int on);
+int crt_counters(crt_ctx *ctx, uint64_t out[CRT_NCOUNTERS]);
+int crt_reset_counters(crt_ctx *ctx);
+
+/* Device time of the kernels enqueued by the LAST crt_trace call (HIP events
+ * on the context's stream), and how many kernel launches that was. */
+int crt_last_trace_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
+
+/* Tuning knobs.  "spp_per_launch": samples fused per kernel launch (0 = default). */
+int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);
+
+/* Accel statistics: out[0]=nodes, [1]=leaves, [2]=max depth, [3]=bytes. */
+int crt_accel_stats(crt_ctx *ctx, uint64_t out[4]);
+
+/* Test hooks: one closest-hit query per ray through the product's traversal
+ * (rays: n x 8 floats ox,oy,oz,dx,dy,dz,exclude_as_u32_bits,_;  out: n x 8:
+ * t, px,py,pz, nx,ny,nz, index_bits (0xFFFFFFFF = miss)); and elementwise
+ * evaluation of the device math (fn codes: 0 sin 1 cos 2 exp 3 log2 4 exp2
+ * 5 pow 6 sqrt 7 div 8 tan). */
+int crt_debug_intersect(crt_ctx *ctx, const float *rays, size_t n, float *out);
+int crt_debug_math(crt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H */

@@ -273,6 +273,8 @@ typedef struct {
     uint32_t sample;
     float hit_pad;
     uint64_t c_rays, c_tests, c_bounces, c_shadow, c_rand;
+    float *raylog;            /* optional: 12 floats per intersect() call */
+    uint32_t raylog_cap, raylog_n;
 } tstate;
 
 /* CS:893-897 */
@@ -433,6 +435,15 @@ static isect_t intersect(tstate *ts, const ray_t *ray, uint32_t exclude)
     }
     ts->c_rays++;
     ts->c_tests += sc->nprim;
+    if (ts->raylog && ts->raylog_n < ts->raylog_cap) {
+        float *l = ts->raylog + (size_t)ts->raylog_n * 12;
+        uint32_t idx = r.ctx.hit ? r.ctx.index : MAX_U32;
+        l[0] = ray->origin.x; l[1] = ray->origin.y; l[2] = ray->origin.z;
+        l[3] = ray->direction.x; l[4] = ray->direction.y; l[5] = ray->direction.z;
+        memcpy(&l[6], &exclude, 4); memcpy(&l[7], &idx, 4);
+        l[8] = r.ctx.t_max; l[9] = r.si.normal.x; l[10] = r.si.normal.y; l[11] = r.si.normal.z;
+        ts->raylog_n++;
+    }
     return r;
 }
 
@@ -850,6 +861,22 @@ int orc_trace_pixel(const orc_scene *sc, uint32_t x, uint32_t y, uint32_t sample
     pixel_sample(&ts, x, y, W, H, frame, out);
     out->n_rand = (uint32_t)ts.c_rand;
     return 0;
+}
+
+/* Every intersect() call of one pixel-sample, in order: 12 floats each =
+ * o.xyz, d.xyz, exclude bits, hit index bits (0xFFFFFFFF = miss), t, normal.xyz */
+int orc_ray_log(const orc_scene *sc, uint32_t x, uint32_t y, uint32_t sample, float *log,
+                uint32_t cap)
+{
+    if (!scene_ok(sc) || !log) return -1;
+    uint32_t W = (uint32_t)sc->camera[11], H = (uint32_t)sc->camera[12];
+    float frame[12];
+    orc_camera_frame(sc->camera, frame);
+    tstate ts; memset(&ts, 0, sizeof ts);
+    ts.sc = sc; ts.hit_pad = orc_hit_pad(sc); ts.sample = sample;
+    ts.raylog = log; ts.raylog_cap = cap;
+    pixel_sample(&ts, x, y, W, H, frame, NULL);
+    return (int)ts.raylog_n;
 }
 
 int orc_intersect(const orc_scene *sc, const float o[3], const float d[3], uint32_t exclude,

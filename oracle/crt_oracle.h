@@ -65,6 +65,12 @@ typedef struct {
 int orc_trace_pixel(const orc_scene *sc, uint32_t x, uint32_t y, uint32_t sample,
                     orc_transcript *out);
 
+/* Every intersect() call of one pixel-sample, in order; 12 floats per ray:
+ * o.xyz, d.xyz, exclude bits, hit index bits (0xFFFFFFFF = miss), t, normal.xyz.
+ * Returns the number of rays logged (<= cap) or -1. */
+int orc_ray_log(const orc_scene *sc, uint32_t x, uint32_t y, uint32_t sample, float *log,
+                uint32_t cap);
+
 /* One closest-hit query with the reference's brute-force loop (for BVH tests).
  * out_f: t, px,py,pz, nx,ny,nz ; out_u: hit, index, material, emission, reflectance */
 int orc_intersect(const orc_scene *sc, const float o[3], const float d[3],

@@ -65,6 +65,8 @@ def lib():
         L.orc_intersect.restype = C.c_int
         L.orc_intersect.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_void_p]
+        L.orc_ray_log.restype = C.c_int
+        L.orc_ray_log.argtypes = [C.POINTER(_Scene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_tea.restype = C.c_uint32
         L.orc_tea.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_rand_kat.restype = None
@@ -127,6 +129,14 @@ class Scene:
         if lib().orc_trace_pixel(C.byref(self.c), x, y, sample, C.byref(t)) != 0:
             raise RuntimeError("orc_trace_pixel failed")
         return t
+
+    def ray_log(self, x, y, sample=1, cap=512) -> np.ndarray:
+        """[n,12] float32: o, d, exclude bits, hit index bits, t, normal."""
+        log = np.zeros((cap, 12), np.float32)
+        n = lib().orc_ray_log(C.byref(self.c), x, y, sample, log.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("orc_ray_log failed")
+        return log[:n]
 
     def intersect(self, o, d, exclude=MAX_U32):
         o = np.ascontiguousarray(o, np.float32)
