@@ -153,7 +153,9 @@ def make_primitives(category, data1, data2, data3, emission, reflectance, materi
 def lights_of(primitives: np.ndarray) -> np.ndarray:
     """main.js:255-296: every primitive whose type is 'light', packed as a patch
     (category word written as 0)."""
-    sel = primitives[primitives["data4"][:, 2] == TYPE_INDEX["light"]].copy()
+    mask = primitives["data4"][:, 2] == TYPE_INDEX["light"]
+    sel = np.zeros(int(mask.sum()), PRIM_DTYPE)
+    sel[:] = primitives[mask]
     sel["category"] = 0
     return sel
 

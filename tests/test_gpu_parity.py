@@ -1,0 +1,282 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the
+C ABI against the CPU oracle on the same inputs -- bit-exact on the f32 XYZ
+accumulator and on every rgba8 byte -- plus size-independent properties at the
+benchmark sizes (tile-partition invariance, fused-vs-incremental samples,
+BVH == the reference's own loop)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+
+pytestmark = pytest.mark.gpu
+
+MAXU = 0xFFFFFFFF
+
+
+def assert_same_image(acc, rgba, acc_o, rgba_o, rect=None):
+    if rect is not None:
+        x0, y0, x1, y1 = rect
+        acc_o, rgba_o = acc_o[y0:y1, x0:x1], rgba_o[y0:y1, x0:x1]
+    bad = (bits(acc)[..., :3] != bits(acc_o)[..., :3]).any(-1)
+    assert not bad.any(), f"{int(bad.sum())} accumulator pixels differ, first at {np.argwhere(bad)[0][::-1]}"
+    assert np.array_equal(rgba, rgba_o), f"{int((rgba != rgba_o).sum())} rgba8 bytes differ"
+
+
+def render(r, ps, spp, mode="bvh2", tile=None):
+    r.upload(ps)
+    if tile is not None:
+        r.set_tile(*tile)
+    r.build_accel(mode)
+    r.frame(spp).sync()
+    return r.read_accum(), r.read_rgba8()
+
+
+# ------------------------------------------------------------------ numerics layer
+def test_device_math_is_bit_exact(renderer, orc):
+    rng = np.random.default_rng(1)
+    n = 1 << 18
+    cases = [("sin", 0, rng.uniform(0, 6.3, n), None), ("cos", 1, rng.uniform(0, 6.3, n), None),
+             ("exp", 2, rng.uniform(-110, 90, n), None), ("log2", 3, np.exp(rng.uniform(-95, 88, n)), None),
+             ("exp2", 4, rng.uniform(-155, 130, n), None),
+             ("pow", 5, np.exp(rng.uniform(-10, 10, n)), rng.uniform(-3, 3, n)),
+             ("sqrt", 6, np.exp(rng.uniform(-95, 88, n)), None),
+             ("div", 7, rng.normal(size=n) * 1e3, np.exp(rng.uniform(-30, 30, n))),
+             ("tan", 8, rng.uniform(0, 1.5, n), None)]
+    for name, code, a, b in cases:
+        a = a.astype(np.float32)
+        b = None if b is None else b.astype(np.float32)
+        assert np.array_equal(bits(renderer.debug_math(code, a, b)), bits(orc.math_eval(name, a, b))), name
+    # denormal results and special values go the same way on both sides
+    a = np.float32([1e-30, 1e-38, 3e-39, 0.0, 1e30, np.inf, np.nan, -1.0])
+    b = np.float32([1e10, 1e5, 7.0, 1.0, 1e-10, 2.0, 1.0, 0.0])
+    assert np.array_equal(bits(renderer.debug_math(7, a, b)), bits(orc.math_eval("div", a, b)))
+    assert np.array_equal(bits(renderer.debug_math(2, np.float32([-100, -103.9, -90]))),
+                          bits(orc.math_eval("exp", np.float32([-100, -103.9, -90]))))
+
+
+# ------------------------------------------------------------------ reference scene
+@pytest.mark.parametrize("mode", ["none", "bvh2"])
+def test_cornell_matches_committed_golden(renderer, golden_buffers, golden_256, mode):
+    """Against tests/golden (no oracle at run time): spp 1, 2, 16, 17 (17 wraps sample % 16)."""
+    from computeraytracer_amd.scene import PackedScene, PRIM_DTYPE
+    b = golden_buffers
+    ps = PackedScene(b["primitives"].view(PRIM_DTYPE), b["lights"].view(PRIM_DTYPE), b["camera"], b["spectra"], b["cie"])
+    renderer.upload(ps).build_accel(mode)
+    done = 0
+    for spp in (1, 2, 16, 17):
+        renderer.frame(spp - done).sync()          # progressive, like the reference's frame loop
+        done = spp
+        acc, rgba = renderer.read_accum(), renderer.read_rgba8()
+        assert np.array_equal(rgba, golden_256[f"rgba_{spp}"])
+        assert np.array_equal(bits(acc[112:144, 112:144]), bits(golden_256[f"accum_crop_{spp}"]))
+        np.testing.assert_allclose(acc.astype(np.float64).sum((0, 1)), golden_256[f"accum_sum_{spp}"], rtol=1e-12)
+    with open(os.path.join(GOLDEN, "probes.json")) as f:
+        probes = json.load(f)["probe_pixels"]
+    want = golden_256["accum_probe_17"]
+    got = np.asarray([acc[y, x] for x, y in probes])
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_cornell_native_size_vs_oracle(renderer, orc):
+    """The reference's own configuration: 1000 x 1000 (cornell.json camera)."""
+    from computeraytracer_amd import cornell
+    ps = cornell()
+    assert (ps.width, ps.height) == (1000, 1000)
+    acc_o, rgba_o, cnt_o = orc.Scene.from_packed(ps).render(2)
+    renderer.upload(ps).build_accel("bvh2").enable_counters(True).reset_counters()
+    renderer.frame(2).sync()
+    c = renderer.counters()
+    renderer.enable_counters(False)
+    assert_same_image(renderer.read_accum(), renderer.read_rgba8(), acc_o, rgba_o)
+    assert (c["rays"], c["paths"], c["bounces"], c["shadow"]) == (int(cnt_o[0]), int(cnt_o[2]), int(cnt_o[3]), int(cnt_o[4]))
+
+
+def test_ragged_size_and_brute_mode(renderer, orc):
+    """Width/height not multiples of the 8x8 tile; the reference loop on the GPU."""
+    from computeraytracer_amd import cornell
+    ps = cornell(250, 131)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(3)
+    for mode in ("none", "bvh2"):
+        acc, rgba = render(renderer, ps, 3, mode)
+        assert acc.shape == (131, 250, 4)
+        assert_same_image(acc, rgba, acc_o, rgba_o)
+
+
+# ------------------------------------------------------------------ triangle scenes
+def _crops_vs_oracle(renderer, orc, ps, spp, crops):
+    acc, rgba = render(renderer, ps, spp)
+    sc = orc.Scene.from_packed(ps)
+    for rect in crops:
+        acc_o, rgba_o, _ = sc.render(spp, rect=rect)
+        x0, y0, x1, y1 = rect
+        assert_same_image(acc[y0:y1, x0:x1], rgba[y0:y1, x0:x1], acc_o, rgba_o, rect)
+
+
+def test_mesh10k_1080p_crops_vs_oracle(renderer, orc):
+    """BASELINE config 2 (10k-tri mesh, 1920x1080): GPU renders the full frame, the
+    brute-force oracle re-renders crops of it."""
+    from computeraytracer_amd.scenes_synth import mesh10k
+    ps = mesh10k(1920, 1080)
+    assert len(ps.primitives) == 6 + 10368
+    _crops_vs_oracle(renderer, orc, ps, 2, [(900, 500, 948, 532), (700, 620, 748, 652), (1200, 200, 1232, 232),
+                                            (0, 0, 16, 16), (1904, 1064, 1920, 1080)])
+
+
+def test_atrium250k_1080p_crops_vs_oracle(renderer, orc):
+    """BASELINE config 3 scene (250k tris, deep BVH) at 1080p."""
+    from computeraytracer_amd.scenes_synth import atrium250k
+    ps = atrium250k(1920, 1080)
+    assert len(ps.primitives) == 6 + 253952
+    _crops_vs_oracle(renderer, orc, ps, 1, [(940, 600, 972, 616), (700, 400, 732, 416), (1100, 820, 1132, 836)])
+
+
+def test_soup_vs_oracle(renderer, orc):
+    """BASELINE config 5 generator at reduced count (random-triangle soup)."""
+    from computeraytracer_amd.scenes_synth import soup
+    ps = soup(200_000, 96, 54)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(2)
+    acc, rgba = render(renderer, ps, 2)
+    assert_same_image(acc, rgba, acc_o, rgba_o)
+
+
+def _mixed_scene(w, h):
+    """Patches + a glass and a diffuse sphere + triangles in one BVH."""
+    from computeraytracer_amd import scene as S
+    from computeraytracer_amd.scenes_synth import mesh10k
+    base = mesh10k(w, h)
+    idx = base.spectrum_index
+    sph = S.make_primitives([1, 1], [[120, 90, 150], [430, 110, 180]], [[60] * 3, [75] * 3], [[0] * 3] * 2,
+                            [idx["dark"]] * 2, [idx["red"], idx["white"]], [0, 2], first_index=len(base.primitives))
+    prims = np.zeros(len(base.primitives) + 2, S.PRIM_DTYPE)
+    prims[:-2] = base.primitives
+    prims[-2:] = sph
+    return S.PackedScene(prims, S.lights_of(prims), base.camera, base.spectra, base.cie)
+
+
+def test_mixed_categories_with_glass(renderer, orc):
+    ps = _mixed_scene(160, 90)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(4)
+    acc, rgba = render(renderer, ps, 4)
+    assert_same_image(acc, rgba, acc_o, rgba_o)
+
+
+def test_no_primitives(renderer, orc):
+    """Empty primitive array (only the light record): every ray misses."""
+    from computeraytracer_amd import cornell, scene as S
+    c = cornell(40, 24)
+    ps = S.PackedScene(np.zeros(0, S.PRIM_DTYPE), c.lights, c.camera, c.spectra, c.cie)
+    for mode in ("none", "bvh2"):
+        acc, rgba = render(renderer, ps, 2, mode)
+        assert not acc.any() and not rgba[..., :3].any() and (rgba[..., 3] == 255).all()
+
+
+# ------------------------------------------------------------------ ray level
+def test_bvh_equals_reference_loop_ray_level(renderer, orc):
+    """Closest hit through the BVH == the reference's loop over every primitive
+    (GPU brute force), incl. the tie rule, exclude and NaN rays; and the GPU
+    loop == the oracle's."""
+    ps = _mixed_scene(64, 36)
+    rng = np.random.default_rng(5)
+    n = 400_000
+    o = rng.uniform(-50, 600, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # axis-parallel and grazing rays, rays on the coplanar light/ceiling pair, NaN rays
+    d[:2000] = np.float32([0, 1, 0]); o[:2000, 1] = rng.uniform(0, 500, 2000)
+    d[2000:3000] = np.float32([1, 0, 0]); d[3000:4000] = np.float32([0, 0, -1])
+    d[4000:4100] = np.nan
+    excl = np.full(n, MAXU, np.uint32)
+    excl[::7] = rng.integers(0, len(ps.primitives), len(excl[::7]))
+    renderer.upload(ps).build_accel("bvh2")
+    bvh = renderer.debug_intersect(o, d, excl)
+    renderer.build_accel("none")
+    brute = renderer.debug_intersect(o, d, excl)
+    hit = brute[:, 7].view(np.uint32) != MAXU
+    assert np.array_equal(bvh[:, 7].view(np.uint32), brute[:, 7].view(np.uint32))
+    fin = hit & ~np.isnan(d).any(1)
+    assert np.array_equal(bits(bvh[fin]), bits(brute[fin]))
+    assert 0.2 < hit.mean() < 1.0
+    sc = orc.Scene.from_packed(ps)
+    for i in list(range(0, 6000, 40)) + list(range(6000, n, 4001)):
+        of, ou = sc.intersect(o[i], d[i], int(excl[i]))
+        gi = int(brute[i, 7:8].view(np.uint32)[0])
+        assert gi == (int(ou[1]) if ou[0] else MAXU)
+        if ou[0] and not np.isnan(d[i]).any():      # NaN payloads are not part of the contract
+            assert np.array_equal(bits(brute[i, :7]), bits(of))
+
+
+# ------------------------------------------------------------------ properties at benchmark sizes
+def test_tile_partition_is_bit_identical_1080p(renderer):
+    """A tile is the same pixels of the full frame (seeds use global coordinates)."""
+    from computeraytracer_amd.scenes_synth import atrium250k
+    ps = atrium250k(1920, 1080)
+    full_acc, full_rgba = render(renderer, ps, 2)
+    for rect in [(0, 0, 1920, 135), (0, 945, 1920, 1080), (333, 217, 1001, 403)]:
+        renderer.set_tile(*rect)
+        renderer.frame(2).sync()
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(bits(renderer.read_accum()), bits(full_acc[y0:y1, x0:x1]))
+        assert np.array_equal(renderer.read_rgba8(), full_rgba[y0:y1, x0:x1])
+
+
+def test_fused_samples_equal_incremental_frames(renderer):
+    from computeraytracer_amd.scenes_synth import mesh10k
+    ps = mesh10k(480, 270)
+    a17, r17 = render(renderer, ps, 17)
+    renderer.reset()
+    for _ in range(17):
+        renderer.frame(1)
+    renderer.sync()
+    assert np.array_equal(bits(renderer.read_accum()), bits(a17)) and np.array_equal(renderer.read_rgba8(), r17)
+    renderer.reset().set_option("spp_per_launch", 5)
+    renderer.frame(17).sync()
+    renderer.set_option("spp_per_launch", 0)
+    assert np.array_equal(bits(renderer.read_accum()), bits(a17)) and np.array_equal(renderer.read_rgba8(), r17)
+    assert renderer.sample == 17
+
+
+def test_bvh_equals_reference_loop_image_level(renderer):
+    """Whole-image form of the BVH contract on a window of the 1080p frame."""
+    from computeraytracer_amd.scenes_synth import atrium250k
+    ps = atrium250k(1920, 1080)
+    tile = (832, 476, 1088, 604)
+    a_bvh, r_bvh = render(renderer, ps, 1, "bvh2", tile)
+    a_ref, r_ref = render(renderer, ps, 1, "none", tile)
+    assert np.array_equal(bits(a_bvh), bits(a_ref)) and np.array_equal(r_bvh, r_ref)
+
+
+def test_checkpoint_resume(renderer):
+    """accum + sample index is a resumable checkpoint."""
+    from computeraytracer_amd import cornell
+    ps = cornell(128, 128)
+    a8, r8 = render(renderer, ps, 8)
+    renderer.reset().frame(5).sync()
+    ckpt = renderer.read_accum()
+    renderer.reset()
+    renderer.write_accum(ckpt, 5).frame(3).sync()
+    assert np.array_equal(bits(renderer.read_accum()), bits(a8)) and np.array_equal(renderer.read_rgba8(), r8)
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_errors_are_reported_not_fatal():
+    from computeraytracer_amd import Renderer, cornell, scene as S
+    from computeraytracer_amd._lib import CrtError
+    r = Renderer(0)
+    with pytest.raises(CrtError, match="upload a scene first"):
+        r.frame(1)
+    ps = cornell(32, 32)
+    r.upload(ps)
+    with pytest.raises(CrtError, match="crt_build_accel first"):
+        r.frame(1)
+    bad = ps.primitives.copy()
+    bad["data4"][3, 3] = 9
+    with pytest.raises(CrtError, match="must equal the array position"):
+        r.upload(S.PackedScene(bad, ps.lights, ps.camera, ps.spectra, ps.cie))
+    with pytest.raises(CrtError, match="outside"):
+        r.upload(ps).set_tile(0, 0, 64, 8)
+    r.upload(ps).build_accel("bvh2").frame(1).sync()       # still usable afterwards
+    assert r.read_rgba8().shape == (32, 32, 4)
+    r.close()
