@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the path-trace pass on the 250k-triangle scene at
+1920x1080 (BASELINE.json metric), with the HBM roofline of the trace kernel and a
+CPU baseline (the brute-force oracle) timed on the box's host cores.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  A "step" = `--spp` more samples of the whole frame
+(progressive, like the reference's frame loop, main.js:584-621), the frame
+partitioned into horizontal strips across ranks (scene replicated; RNG seeds use
+global pixel coordinates so the image is bit-identical for every N), followed by
+the RCCL gather of the strips.  Total work is fixed as N grows: scaling = strong.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="atrium250k", choices=["cornell", "mesh10k", "atrium250k", "soup"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="samples per step (BASELINE config 3: 64)")
+    ap.add_argument("--soup-tris", type=int, default=10_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", default="128x72", help="oracle sample: centre crop WxH at 1 spp")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from computeraytracer_amd import Renderer, scenes_synth
+    from computeraytracer_amd.partition import strip_rows
+
+    W, H = args.width, args.height
+    if args.scene == "soup":
+        ps = scenes_synth.soup(args.soup_tris, W, H)
+    else:
+        ps = scenes_synth.SCENES[args.scene](W, H)
+    ntri = int((ps.primitives["category"] == 2).sum())
+
+    r = Renderer(local_rank)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.upload(ps)
+    y0, y1 = strip_rows(H, world, rank)
+    rows_max = strip_rows(H, world, 0)[1]
+    r.set_tile(0, y0, W, y1)
+    t0 = time.time()
+    r.build_accel("bvh2")
+    t_build = time.time() - t0
+    # strips live in torch tensors (padded to equal size) so RCCL can gather them
+    accum_t = torch.zeros((rows_max, W, 4), dtype=torch.float32, device=dev)
+    rgba_t = torch.zeros((rows_max, W, 4), dtype=torch.uint8, device=dev)
+    r.bind_output(accum_t.data_ptr(), rgba_t.data_ptr())
+    if world > 1:
+        full_accum = torch.empty((world, rows_max, W, 4), dtype=torch.float32, device=dev)
+        full_rgba = torch.empty((world, rows_max, W, 4), dtype=torch.uint8, device=dev)
+
+    def step():
+        r.frame(args.spp)
+        if world > 1:       # the path's one exchange step: gather the strips (RCCL over xGMI)
+            dist.all_gather_into_tensor(full_accum, accum_t)
+            dist.all_gather_into_tensor(full_rgba, rgba_t)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    r.reset()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms, nl = r.last_trace_ms()         # HIP events on the launch stream (waits for this step's kernels)
+        kernel_ms += ms
+        launches += nl
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Ray / node / primitive counts of exactly the timed samples: the path is a pure function of
+    # (scene, pixel, sample), so re-running the same sample range with the counting kernel
+    # variant (untimed) gives the exact counts.
+    r.reset()
+    r.write_accum(np.zeros((y1 - y0, W, 4), np.float32), args.warmup * args.spp)
+    r.enable_counters(True).reset_counters()
+    for _ in range(args.steps):
+        r.frame(args.spp)
+    r.sync()
+    c = r.counters()
+    r.enable_counters(False)
+    cnt = torch.tensor([c["rays"], c["nodes"], c["prims"], c["hits"], c["paths"], c["shadow"]], dtype=torch.float64, device=dev)
+    mine = cnt.clone()
+    if world > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    rays, nodes, prims, hits, paths, shadow = [float(v) for v in cnt.tolist()]
+
+    if rank == 0:
+        mrays = rays / elapsed / 1e6
+        # roofline of the trace kernel on THIS rank: algorithmic bytes per launch
+        # over the average launch duration measured with HIP events inside the timed region.
+        m_rays, m_nodes, m_prims, m_hits, m_paths, _ = [float(v) for v in mine.tolist()]
+        px_launches = float((y1 - y0) * W) * launches
+        alg_bytes = 32.0 * m_nodes + 48.0 * m_prims + 16.0 * m_hits + 36.0 * px_launches
+        per_launch = alg_bytes / max(launches, 1)
+        avg_ms = kernel_ms / max(launches, 1)
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/sec (+ HBM GB/s vs peak), 1080p 250k-tri scene, 1/2/4/8 MI355X",
+            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S2 {args.scene}: {ntri} triangles + cornell walls/light, {W}x{H}, "
+                                   f"{args.spp} spp per step (BASELINE config 3)" if args.scene == "atrium250k" else
+                                   f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
+                       "partition": f"{world} horizontal strip(s), scene replicated, all_gather of strips per step",
+                       "accel": "BVH2 binned SAH (host build %.2f s)" % t_build},
+            "mpaths_per_s": round(paths / elapsed / 1e6, 3),
+            "rays_per_path": round(rays / max(paths, 1), 3),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "k_trace", "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": round(per_launch),
+                         "bytes_per_ray": round(alg_bytes / max(m_rays, 1), 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ps, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+def cpu_baseline(ps, args):
+    """The CPU restatement of the reference shader (oracle, brute force = the reference's
+    algorithm) on a bounded sample of the same workload, all host cores."""
+    from oracle import orc
+    cw, ch = [int(v) for v in args.cpu_crop.split("x")]
+    W, H = ps.width, ps.height
+    x0, y0 = (W - cw) // 2, (H - ch) // 2 + H // 8
+    sc = orc.Scene.from_packed(ps)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    _, _, cnt = sc.render(1, rect=(x0, y0, x0 + cw, y0 + ch))
+    dt = time.perf_counter() - t0
+    return {"value": round(float(cnt[0]) / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{cw}x{ch} crop at ({x0},{y0}) of the same frame, 1 spp, brute force over all "
+                      f"{len(ps.primitives)} primitives (the reference's O(N) loop), {float(cnt[1]):.3g} "
+                      f"primitive tests in {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

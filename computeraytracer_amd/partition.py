@@ -1,0 +1,34 @@
+"""Image-tile partition of the framebuffer across GPUs.
+
+Pixels are independent (a pixel depends only on x, y, sample, W, H and the
+scene: ComputeShader.wgsl:85-86,98,107), so the frame splits into per-rank
+horizontal strips with the scene replicated and no data-path collective; the
+only exchange is the gather of finished strips.
+"""
+from __future__ import annotations
+
+
+def strip_rows(height: int, world: int, rank: int) -> tuple[int, int]:
+    """Rows [y0, y1) of rank `rank`: ceil(H/world) rows each, the last ranks may be short/empty."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    per = -(-height // world)
+    y0 = min(rank * per, height)
+    return y0, min(y0 + per, height)
+
+
+def assemble(strips, height: int):
+    """Concatenate gathered (padded) strips [world, rows_max, W, C] back into [H, W, C]."""
+    world = strips.shape[0]
+    parts = []
+    for r in range(world):
+        y0, y1 = strip_rows(height, world, r)
+        parts.append(strips[r, : y1 - y0])
+    import numpy as np
+    try:
+        import torch
+        if isinstance(strips, torch.Tensor):
+            return torch.cat(parts, 0)
+    except ImportError:
+        pass
+    return np.concatenate(parts, 0)
