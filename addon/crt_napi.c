@@ -1,0 +1,378 @@
+/*
+ * crt_napi.c -- thin N-API addon: 1:1 JavaScript wrappers over the C ABI of
+ * include/crt.h (libcrt.so, hand-written HIP for gfx950).
+ *
+ * It stands where the reference's src/main.js talks to WebGPU:
+ *   navigator.gpu.requestAdapter/requestDevice (main.js:8-9)        -> create()
+ *   createBuffer + getMappedRange + unmap for b4..b8 (main.js:147-393) -> uploadScene()
+ *   dispatchWorkgroups(1); dispatchWorkgroups(W/8,H/8) (main.js:598-611) -> trace(n)
+ *   "uncapturederror" (main.js:11-14)                               -> thrown Error
+ * Build: plain gcc against /usr/include/node (no node-gyp), see addon/Makefile.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/crt.h"
+
+#define NAPI_OK(env, call)                                                          \
+    do {                                                                            \
+        if ((call) != napi_ok) {                                                    \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);             \
+            return NULL;                                                            \
+        }                                                                           \
+    } while (0)
+
+static napi_value throw_crt(napi_env env, crt_ctx *ctx, int code, const char *what)
+{
+    char msg[640];
+    const char *detail = crt_last_error(ctx);
+    snprintf(msg, sizeof msg, "%s failed (%d): %s", what, code, detail ? detail : "");
+    napi_throw_error(env, "ERR_CRT", msg);
+    return NULL;
+}
+
+#define CRT_CHECK(env, ctx, what, call)                                  \
+    do {                                                                 \
+        int rc_ = (call);                                                \
+        if (rc_ != CRT_OK) return throw_crt((env), (ctx), rc_, (what));  \
+    } while (0)
+
+static void finalize_ctx(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    crt_ctx **slot = (crt_ctx **)data;
+    if (slot) {
+        if (*slot) crt_destroy(*slot);
+        free(slot);
+    }
+}
+
+/* args[0] is always the handle (an external holding crt_ctx**) */
+static crt_ctx *get_ctx(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*(crt_ctx **)p) {
+        napi_throw_type_error(env, NULL, "invalid or destroyed crt context handle");
+        return NULL;
+    }
+    return *(crt_ctx **)p;
+}
+
+/* Bytes of an ArrayBuffer / TypedArray / DataView / Buffer argument. */
+static int get_bytes(napi_env env, napi_value v, void **data, size_t *len)
+{
+    bool is;
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is)
+        return napi_get_arraybuffer_info(env, v, data, len) == napi_ok;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type t; size_t n, off; napi_value ab;
+        if (napi_get_typedarray_info(env, v, &t, &n, data, &ab, &off) != napi_ok) return 0;
+        static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        *len = n * esz[t];
+        return 1;
+    }
+    if (napi_is_dataview(env, v, &is) == napi_ok && is) {
+        napi_value ab; size_t off;
+        return napi_get_dataview_info(env, v, len, data, &ab, &off) == napi_ok;
+    }
+    if (napi_is_buffer(env, v, &is) == napi_ok && is)
+        return napi_get_buffer_info(env, v, data, len) == napi_ok;
+    return 0;
+}
+
+#define ARGS(n)                                                       \
+    size_t argc = (n);                                                \
+    napi_value argv[(n) > 0 ? (n) : 1];                               \
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL)); \
+    if (argc < (size_t)(n)) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
+
+static napi_value undefined(napi_env env)
+{
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    int32_t dev = 0;
+    NAPI_OK(env, napi_get_value_int32(env, argv[0], &dev));
+    crt_ctx *ctx = NULL;
+    int rc = crt_create(&ctx, dev);
+    if (rc != CRT_OK) return throw_crt(env, NULL, rc, "crt_create");
+    crt_ctx **slot = (crt_ctx **)malloc(sizeof *slot);
+    *slot = ctx;
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, slot, finalize_ctx, NULL, &ext));
+    return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    void *p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && *(crt_ctx **)p) {
+        crt_destroy(*(crt_ctx **)p);
+        *(crt_ctx **)p = NULL;
+    }
+    return undefined(env);
+}
+
+/* uploadScene(h, primitives, lights, spectra, cie, camera) -- byte buffers exactly as
+ * main.js builds them (80-byte records; Float32Array tables). */
+static napi_value js_upload_scene(napi_env env, napi_callback_info info)
+{
+    ARGS(6)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p[5]; size_t n[5];
+    static const char *names[5] = {"primitives", "lights", "spectra", "cie", "camera"};
+    for (int i = 0; i < 5; i++) {
+        if (!get_bytes(env, argv[i + 1], &p[i], &n[i])) {
+            char m[96];
+            snprintf(m, sizeof m, "uploadScene: %s must be an ArrayBuffer or typed array", names[i]);
+            napi_throw_type_error(env, NULL, m);
+            return NULL;
+        }
+    }
+    if (n[0] % 80 || n[1] % 80 || n[2] % (301 * 4) || n[3] != 3 * 471 * 4 || n[4] != 64) {
+        napi_throw_range_error(env, NULL, "uploadScene: sizes must be primitives/lights k*80 B, spectra k*1204 B, "
+                                          "cie 5652 B, camera 64 B");
+        return NULL;
+    }
+    CRT_CHECK(env, ctx, "crt_upload_scene",
+              crt_upload_scene(ctx, p[0], n[0] / 80, p[1], n[1] / 80, (const float *)p[2], n[2] / (301 * 4),
+                               (const float *)p[3], (const float *)p[4]));
+    return undefined(env);
+}
+
+static napi_value js_set_tile(napi_env env, napi_callback_info info)
+{
+    ARGS(5)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t v[4];
+    for (int i = 0; i < 4; i++) NAPI_OK(env, napi_get_value_uint32(env, argv[i + 1], &v[i]));
+    CRT_CHECK(env, ctx, "crt_set_tile", crt_set_tile(ctx, v[0], v[1], v[2], v[3]));
+    return undefined(env);
+}
+
+static napi_value js_build_accel(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t mode;
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &mode));
+    CRT_CHECK(env, ctx, "crt_build_accel", crt_build_accel(ctx, mode));
+    return undefined(env);
+}
+
+static napi_value js_reset(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    CRT_CHECK(env, ctx, "crt_reset", crt_reset(ctx));
+    return undefined(env);
+}
+
+static napi_value js_trace(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t n;
+    NAPI_OK(env, napi_get_value_uint32(env, argv[1], &n));
+    CRT_CHECK(env, ctx, "crt_trace", crt_trace(ctx, n));
+    return undefined(env);
+}
+
+static napi_value js_sync(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    CRT_CHECK(env, ctx, "crt_sync", crt_sync(ctx));
+    return undefined(env);
+}
+
+static napi_value js_sample_count(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t s = 0;
+    CRT_CHECK(env, ctx, "crt_sample_count", crt_sample_count(ctx, &s));
+    napi_value out;
+    NAPI_OK(env, napi_create_uint32(env, s, &out));
+    return out;
+}
+
+static napi_value js_tile(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t t[4];
+    CRT_CHECK(env, ctx, "crt_tile", crt_tile(ctx, t));
+    napi_value arr;
+    NAPI_OK(env, napi_create_array_with_length(env, 4, &arr));
+    for (uint32_t i = 0; i < 4; i++) {
+        napi_value v;
+        NAPI_OK(env, napi_create_uint32(env, t[i], &v));
+        NAPI_OK(env, napi_set_element(env, arr, i, v));
+    }
+    return arr;
+}
+
+static napi_value read_image(napi_env env, napi_callback_info info, int rgba)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t t[4];
+    CRT_CHECK(env, ctx, "crt_tile", crt_tile(ctx, t));
+    size_t px = (size_t)t[2] * t[3];
+    size_t bytes = px * (rgba ? 4 : 16);
+    void *data = NULL;
+    napi_value ab, ta;
+    NAPI_OK(env, napi_create_arraybuffer(env, bytes, &data, &ab));
+    if (rgba) CRT_CHECK(env, ctx, "crt_read_rgba8", crt_read_rgba8(ctx, (uint8_t *)data));
+    else CRT_CHECK(env, ctx, "crt_read_accum", crt_read_accum(ctx, (float *)data));
+    NAPI_OK(env, napi_create_typedarray(env, rgba ? napi_uint8_array : napi_float32_array, px * 4, ab, 0, &ta));
+    return ta;
+}
+static napi_value js_read_accum(napi_env env, napi_callback_info info) { return read_image(env, info, 0); }
+static napi_value js_read_rgba8(napi_env env, napi_callback_info info) { return read_image(env, info, 1); }
+
+static napi_value js_write_accum(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n;
+    uint32_t s, t[4];
+    if (!get_bytes(env, argv[1], &p, &n)) { napi_throw_type_error(env, NULL, "writeAccum: typed array expected"); return NULL; }
+    NAPI_OK(env, napi_get_value_uint32(env, argv[2], &s));
+    CRT_CHECK(env, ctx, "crt_tile", crt_tile(ctx, t));
+    if (n != (size_t)t[2] * t[3] * 16) { napi_throw_range_error(env, NULL, "writeAccum: need tw*th*4 floats"); return NULL; }
+    CRT_CHECK(env, ctx, "crt_write_accum", crt_write_accum(ctx, (const float *)p, s));
+    return undefined(env);
+}
+
+static napi_value js_enable_counters(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    bool on;
+    NAPI_OK(env, napi_get_value_bool(env, argv[1], &on));
+    CRT_CHECK(env, ctx, "crt_enable_counters", crt_enable_counters(ctx, on ? 1 : 0));
+    return undefined(env);
+}
+
+static napi_value js_reset_counters(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    CRT_CHECK(env, ctx, "crt_reset_counters", crt_reset_counters(ctx));
+    return undefined(env);
+}
+
+static napi_value u64_array(napi_env env, const uint64_t *v, uint32_t n)
+{
+    napi_value arr;
+    NAPI_OK(env, napi_create_array_with_length(env, n, &arr));
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value d;
+        NAPI_OK(env, napi_create_double(env, (double)v[i], &d));   /* exact below 2^53 */
+        NAPI_OK(env, napi_set_element(env, arr, i, d));
+    }
+    return arr;
+}
+
+static napi_value js_counters(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint64_t c[CRT_NCOUNTERS];
+    CRT_CHECK(env, ctx, "crt_counters", crt_counters(ctx, c));
+    return u64_array(env, c, CRT_NCOUNTERS);
+}
+
+static napi_value js_accel_stats(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint64_t c[4];
+    CRT_CHECK(env, ctx, "crt_accel_stats", crt_accel_stats(ctx, c));
+    return u64_array(env, c, 4);
+}
+
+static napi_value js_last_trace_ms(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    float ms = 0; uint32_t n = 0;
+    CRT_CHECK(env, ctx, "crt_last_trace_ms", crt_last_trace_ms(ctx, &ms, &n));
+    napi_value arr, a, b;
+    NAPI_OK(env, napi_create_array_with_length(env, 2, &arr));
+    NAPI_OK(env, napi_create_double(env, ms, &a));
+    NAPI_OK(env, napi_create_uint32(env, n, &b));
+    NAPI_OK(env, napi_set_element(env, arr, 0, a));
+    NAPI_OK(env, napi_set_element(env, arr, 1, b));
+    return arr;
+}
+
+static napi_value js_set_option(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    char name[64]; size_t len; int64_t v;
+    NAPI_OK(env, napi_get_value_string_utf8(env, argv[1], name, sizeof name, &len));
+    NAPI_OK(env, napi_get_value_int64(env, argv[2], &v));
+    CRT_CHECK(env, ctx, "crt_set_option", crt_set_option(ctx, name, v));
+    return undefined(env);
+}
+
+static napi_value js_abi_version(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    napi_value v;
+    NAPI_OK(env, napi_create_int32(env, crt_abi_version(), &v));
+    return v;
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    static const struct { const char *name; napi_callback fn; } fns[] = {
+        {"create", js_create}, {"destroy", js_destroy}, {"uploadScene", js_upload_scene},
+        {"setTile", js_set_tile}, {"buildAccel", js_build_accel}, {"reset", js_reset},
+        {"trace", js_trace}, {"sync", js_sync}, {"sampleCount", js_sample_count}, {"tile", js_tile},
+        {"readAccum", js_read_accum}, {"readRgba8", js_read_rgba8}, {"writeAccum", js_write_accum},
+        {"enableCounters", js_enable_counters}, {"resetCounters", js_reset_counters},
+        {"counters", js_counters}, {"accelStats", js_accel_stats}, {"lastTraceMs", js_last_trace_ms},
+        {"setOption", js_set_option}, {"abiVersion", js_abi_version},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+            napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) {
+            napi_throw_error(env, NULL, "crt_napi: export failed");
+            return NULL;
+        }
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

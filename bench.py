@@ -56,7 +56,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from computeraytracer_amd import Renderer, scenes_synth
-    from computeraytracer_amd.partition import strip_rows
+    from computeraytracer_amd.distributed import StripFrame
 
     W, H = args.width, args.height
     if args.scene == "soup":
@@ -68,25 +68,18 @@ def main():
     r = Renderer(local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.upload(ps)
-    y0, y1 = strip_rows(H, world, rank)
-    rows_max = strip_rows(H, world, 0)[1]
-    r.set_tile(0, y0, W, y1)
+    sf = StripFrame(W, H, world, rank, dev)
+    y0, y1 = sf.y0, sf.y1
+    r.set_tile(*sf.tile)
     t0 = time.time()
     r.build_accel("bvh2")
     t_build = time.time() - t0
     # strips live in torch tensors (padded to equal size) so RCCL can gather them
-    accum_t = torch.zeros((rows_max, W, 4), dtype=torch.float32, device=dev)
-    rgba_t = torch.zeros((rows_max, W, 4), dtype=torch.uint8, device=dev)
-    r.bind_output(accum_t.data_ptr(), rgba_t.data_ptr())
-    if world > 1:
-        full_accum = torch.empty((world, rows_max, W, 4), dtype=torch.float32, device=dev)
-        full_rgba = torch.empty((world, rows_max, W, 4), dtype=torch.uint8, device=dev)
+    r.bind_output(sf.accum.data_ptr(), sf.rgba.data_ptr())
 
     def step():
         r.frame(args.spp)
-        if world > 1:       # the path's one exchange step: gather the strips (RCCL over xGMI)
-            dist.all_gather_into_tensor(full_accum, accum_t)
-            dist.all_gather_into_tensor(full_rgba, rgba_t)
+        sf.gather()         # the path's one exchange step: all_gather of the strips (RCCL over xGMI)
 
     def barrier():
         torch.cuda.synchronize()

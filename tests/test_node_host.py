@@ -1,0 +1,32 @@
+"""GPU: the Node host (host/main.js -> N-API addon -> libcrt.so) renders the
+reference scene and matches the oracle bit for bit."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits
+
+pytestmark = pytest.mark.gpu
+NODE = shutil.which("node")
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+@pytest.mark.parametrize("unfused", [False, True])
+def test_node_host_matches_oracle(tmp_path, orc, unfused):
+    from computeraytracer_amd import cornell
+    cmd = [NODE, os.path.join(ROOT, "host", "index.js"), "--width", "96", "--height", "72", "--spp", "3",
+           "--dump", str(tmp_path / "img"), "--out", str(tmp_path / "img.ppm")] + (["--unfused"] if unfused else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["sample"] == 3 and info["width"] == 96 and info["height"] == 72
+    acc = np.frombuffer((tmp_path / "img.accum.bin").read_bytes(), np.float32).reshape(72, 96, 4)
+    rgba = np.frombuffer((tmp_path / "img.rgba8.bin").read_bytes(), np.uint8).reshape(72, 96, 4)
+    acc_o, rgba_o, cnt = orc.Scene.from_packed(cornell(96, 72)).render(3)
+    assert np.array_equal(bits(acc)[..., :3], bits(acc_o)[..., :3]) and np.array_equal(rgba, rgba_o)
+    assert info["rays"] == int(cnt[0])
+    ppm = (tmp_path / "img.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n96 72\n255\n") and len(ppm) == 13 + 96 * 72 * 3
