@@ -41,6 +41,7 @@ SIGNATURES = {
     "crt_counters": (C.c_int, [_P, _P]),
     "crt_reset_counters": (C.c_int, [_P]),
     "crt_last_trace_ms": (C.c_int, [_P, _P, _P]),
+    "crt_last_kernel_ms": (C.c_int, [_P, _P, _P]),
     "crt_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "crt_accel_stats": (C.c_int, [_P, _P]),
     "crt_debug_intersect": (C.c_int, [_P, _P, C.c_size_t, _P]),

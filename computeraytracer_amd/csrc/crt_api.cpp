@@ -24,6 +24,10 @@ hipError_t launch_trace(const TraceParams &P, bool count, bool brute, hipStream_
 hipError_t launch_debug_intersect(const DevScene &S, const float *rays, size_t n, float *out, int brute,
                                   hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
+hipError_t wf_launch_init(const WfParams &P, hipStream_t s);
+hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
+hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
+hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
 }  // namespace crt
 
 using namespace crt;
@@ -104,6 +108,24 @@ struct crt_ctx {
     uint32_t last_launches = 0;
     bool last_timed = false;
     uint32_t spp_per_launch = 0;    // 0 = auto
+
+    // wavefront pipeline (crt_wavefront.hip)
+    int pipeline = 1;               // 1 = wavefront (default), 0 = v1 megakernel
+    uint32_t wf_pool = 0;           // 0 = auto
+    uint32_t wf_waves_per_cu = 16;
+    int num_cu = 0;
+    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging;
+    DevBuf<uint4> w_rng, w_misc;
+    DevBuf<float2> w_hit;
+    DevBuf<uint32_t> w_vis, w_list_ext, w_list_sh;
+    DevBuf<WfCtl> w_ctl;
+    WfCtl *h_ctl = nullptr;         // pinned
+    hipEvent_t ev_ctl = nullptr;
+    bool time_kernels = false;
+    std::vector<hipEvent_t> kev;    // event pairs around k_wf_trace launches
+    float last_trace_kernel_ms = 0.0f;
+    uint32_t last_trace_kernel_launches = 0;
+    uint32_t last_iterations = 0;
 };
 
 namespace {
@@ -304,6 +326,118 @@ int upload_geometry(crt_ctx *c, int mode)
     return CRT_OK;
 }
 
+
+// ---------------------------------------------------------------- wavefront driver
+int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
+{
+    if (c->w_list_ext.n < list_elems) { HIPCHK(c, c->w_list_ext.alloc(list_elems)); HIPCHK(c, c->w_list_sh.alloc(list_elems)); }
+    if (c->w_misc.n < P) {
+        HIPCHK(c, c->w_ray_o.alloc(P)); HIPCHK(c, c->w_ray_d.alloc(P)); HIPCHK(c, c->w_sh_d.alloc(P));
+        HIPCHK(c, c->w_beta.alloc(P)); HIPCHK(c, c->w_radiance.alloc(P)); HIPCHK(c, c->w_nee.alloc(P));
+        HIPCHK(c, c->w_rng.alloc(P)); HIPCHK(c, c->w_misc.alloc(P)); HIPCHK(c, c->w_hit.alloc(P));
+        HIPCHK(c, c->w_vis.alloc(P));
+    }
+    if (c->w_staging.n < staging_elems) HIPCHK(c, c->w_staging.alloc(staging_elems));
+    if (!c->w_ctl.p) {
+        HIPCHK(c, c->w_ctl.alloc(1));
+        HIPCHK(c, hipMemset(c->w_ctl.p, 0, sizeof(WfCtl)));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(WfCtl), hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
+    }
+    if (c->num_cu == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+        c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return CRT_OK;
+}
+
+// One batch of n samples through the wavefront pipeline (asynchronous except for the small
+// control-block readbacks that decide when the pool has drained).
+int wf_trace_batch(crt_ctx *c, uint32_t n)
+{
+    const uint32_t tiles_x = (c->tw + 7) / 8, tiles_y = (c->th + 7) / 8;
+    const uint32_t npix_padded = tiles_x * tiles_y * 64u;
+    const size_t npix = (size_t)c->tw * c->th;
+    if (npix == 0 || n == 0) { c->sample += n; return CRT_OK; }
+    const unsigned long long work_total = (unsigned long long)n * npix_padded;
+    uint32_t P = c->wf_pool ? c->wf_pool : (1u << 21);
+    if ((unsigned long long)P > work_total) P = (uint32_t)work_total;
+    P = (P + 255u) & ~255u;
+    const uint32_t shade_blocks = P / 256u;
+    const uint32_t list_cap = ((shade_blocks + kWfShards - 1) / kWfShards) * 256u;
+    uint32_t work_per_shard = (uint32_t)((work_total + kWfShards - 1) / kWfShards);
+    work_per_shard = (work_per_shard + 63u) & ~63u;
+    int rc = wf_ensure(c, P, (size_t)n * npix, (size_t)list_cap * kWfShards);
+    if (rc) return rc;
+
+    WfParams W{};
+    W.sc = c->sc;
+    W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
+    W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
+    W.hit = c->w_hit.p; W.vis = c->w_vis.p; W.list_ext = c->w_list_ext.p; W.list_sh = c->w_list_sh.p;
+    W.staging = c->w_staging.p; W.ctl = c->w_ctl.p;
+    W.P = P; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
+    W.tiles_x = tiles_x; W.tiles_y = tiles_y; W.npix_padded = npix_padded; W.work_total = work_total;
+    W.work_per_shard = work_per_shard; W.list_cap = list_cap;
+    W.first_sample = c->sample + 1; W.n_samples = n;
+    W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
+    W.count = c->counting ? 1u : 0u;
+    const uint32_t trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
+
+    HIPCHK(c, wf_launch_init(W, c->stream));
+    uint32_t it = 0;
+    uint32_t chunk = 8;
+    for (;;) {
+        for (uint32_t k = 0; k < chunk; k++, it++) {
+            HIPCHK(c, wf_launch_shade(W, it, c->stream));
+            if (c->time_kernels) {
+                size_t need = 2 * (size_t)(c->last_trace_kernel_launches + 1);
+                while (c->kev.size() < need) {
+                    hipEvent_t e;
+                    HIPCHK(c, hipEventCreate(&e));
+                    c->kev.push_back(e);
+                }
+                HIPCHK(c, hipEventRecord(c->kev[need - 2], c->stream));
+            }
+            HIPCHK(c, wf_launch_trace(W, it, trace_blocks, c->stream));
+            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], c->stream));
+            c->last_trace_kernel_launches++;
+            c->last_launches += 2;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev_ctl));
+        bool work_left = false;
+        unsigned long long rays = 0;
+        for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
+            const unsigned long long lo = (unsigned long long)sidx * work_per_shard;
+            const unsigned long long size = lo < work_total ? std::min<unsigned long long>(work_per_shard, work_total - lo) : 0;
+            if (c->h_ctl->work[sidx].cur < size) work_left = true;
+            const WfShard &sh = c->h_ctl->shard[(it - 1) & 1u][sidx];
+            rays += (unsigned long long)sh.n_ext + sh.n_sh;
+        }
+        if (!work_left && rays == 0) break;                     // every slot alive after a shade pass lists a ray
+        if (!work_left) chunk = 2;                               // tail: only long paths are left
+        if (it > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+    }
+    c->last_iterations += it;
+    if (c->counting) {
+        // fold the pipeline's counters into the context's
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        unsigned long long cur[CRT_NCOUNTERS];
+        HIPCHK(c, hipMemcpy(cur, c->d_counters.p, sizeof cur, hipMemcpyDeviceToHost));
+        for (int k = 0; k < CRT_NCOUNTERS; k++) cur[k] += c->h_ctl->counters[k];
+        HIPCHK(c, hipMemcpy(c->d_counters.p, cur, sizeof cur, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemsetAsync(&c->w_ctl.p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS, c->stream));
+    }
+    c->sample += n;
+    HIPCHK(c, wf_launch_resolve(W, c->sample, c->stream));
+    c->last_launches += 2;
+    return CRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +481,12 @@ void crt_destroy(crt_ctx *c)
     c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_lights.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
+    c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
+    c->w_nee.release(); c->w_staging.release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
+    c->w_vis.release(); c->w_list_ext.release(); c->w_list_sh.release(); c->w_ctl.release();
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -468,19 +608,34 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
     P.accum = accum_ptr(c); P.rgba = rgba_ptr(c);
     P.counters = c->counting ? c->d_counters.p : nullptr;
     P.tiles_x = (c->tw + 7) / 8; P.tiles_y = (c->th + 7) / 8;        // main.js:606-610
-    uint32_t chunk = c->spp_per_launch ? c->spp_per_launch : 8u;
     c->last_launches = 0;
     c->last_timed = true;
+    c->last_trace_kernel_launches = 0;
+    c->last_iterations = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t left = n_samples;
-    while (left) {
-        uint32_t n = std::min(left, chunk);
-        P.first_sample = c->sample + 1;                               // UpdateVariables.wgsl: sample++ first
-        P.n_samples = n;
-        HIPCHK(c, launch_trace(P, c->counting, c->accel_mode == CRT_ACCEL_NONE, c->stream));
-        c->sample += n;
-        left -= n;
-        c->last_launches++;
+    if (c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
+        // batch so that the staging buffer stays below ~6 GB and work ids fit 32 bits
+        const size_t npix = std::max<size_t>((size_t)c->tw * c->th, 1);
+        uint32_t cap = (uint32_t)std::max<size_t>(1, std::min<size_t>(256, (size_t)6e9 / (npix * 16)));
+        if (c->spp_per_launch) cap = std::min(cap, c->spp_per_launch);
+        while (left) {
+            uint32_t n = std::min(left, cap);
+            int rc = wf_trace_batch(c, n);
+            if (rc) return rc;
+            left -= n;
+        }
+    } else {
+        uint32_t chunk = c->spp_per_launch ? c->spp_per_launch : 8u;
+        while (left) {
+            uint32_t n = std::min(left, chunk);
+            P.first_sample = c->sample + 1;                               // UpdateVariables.wgsl: sample++ first
+            P.n_samples = n;
+            HIPCHK(c, launch_trace(P, c->counting, c->accel_mode == CRT_ACCEL_NONE, c->stream));
+            c->sample += n;
+            left -= n;
+            c->last_launches++;
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     return CRT_OK;
@@ -610,6 +765,31 @@ int crt_last_trace_ms(crt_ctx *c, float *ms, uint32_t *launches)
     return CRT_OK;
 }
 
+int crt_last_kernel_ms(crt_ctx *c, float *ms, uint32_t *launches)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->last_timed) return fail(c, CRT_ESTATE, "crt_last_kernel_ms: no crt_trace yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float total = 0.0f;
+    uint32_t n = 0;
+    if (c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
+        if (!c->time_kernels) return fail(c, CRT_ESTATE, "crt_last_kernel_ms: set option time_kernels=1 before crt_trace");
+        n = c->last_trace_kernel_launches;
+        for (uint32_t i = 0; i < n; i++) {
+            float t = 0.0f;
+            HIPCHK(c, hipEventElapsedTime(&t, c->kev[2 * (size_t)i], c->kev[2 * (size_t)i + 1]));
+            total += t;
+        }
+    } else {
+        HIPCHK(c, hipEventElapsedTime(&total, c->ev0, c->ev1));
+        n = c->last_launches;
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = n;
+    return CRT_OK;
+}
+
 int crt_accel_stats(crt_ctx *c, uint64_t out[4])
 {
     if (!c || !out) return CRT_EINVAL;
@@ -622,6 +802,10 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return CRT_EINVAL;
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
+    if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
+    if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
+    if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "time_kernels")) { c->time_kernels = value != 0; return CRT_OK; }
     return fail(c, CRT_EINVAL, "crt_set_option: unknown option '%s'", name);
 }
 

@@ -25,6 +25,7 @@ constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kStackDepth = 32;
 constexpr uint32_t kNLambda = 301;
 constexpr uint32_t kNCie = 471;
+constexpr int CRT_NCOUNTERS_DEV = 8;
 
 struct DevScene {
     const float4 *prim;
@@ -52,6 +53,59 @@ struct TraceParams {
     uchar4 *rgba;
     unsigned long long *counters;   // CRT_NCOUNTERS, may be null
     uint32_t tiles_x, tiles_y;
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront pipeline state (crt_wavefront.hip).  A pool of P path slots lives in HBM (SoA,
+// one float4/uint4 per slot per array, so every access is a coalesced 16-byte stream):
+//   ray_o   (o.xyz, exclude bits)         next extension ray of the slot
+//   ray_d   (d.xyz, -)
+//   sh_d    (light dir.xyz, t of the light's own primitive)   pending shadow ray
+//   beta, radiance, nee                   path throughput, radiance, NEE term waiting for visibility
+//   rng     uvec4 PCG state               (ComputeShader.wgsl:899)
+//   misc    (work id, flags, last_bounce_pdf bits, etaScale bits)
+//   hit     (t, hit slot bits)            written by the trace kernel for extension rays
+//   vis     in: light primitive index, out: 1 = light visible    (shadow rays)
+//   list_ext / list_sh                    slots with an active ray this iteration (ballot/popc compacted)
+//   staging (xyz, -) per (sample, pixel)  finished samples, summed in sample order by k_wf_resolve
+constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
+constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
+
+// Every queue counter is sharded kWfShards ways, one 128-byte line per shard: same-address
+// returning atomics serialize at ~11 ns each on gfx950, which at one atomic per wave would
+// cost more than the kernels themselves.  Shade block b appends to shard b % kWfShards of
+// the ray lists; traversal waves and re-arming waves pick a non-empty shard with one
+// wave-wide load + ballot.
+constexpr uint32_t kWfShards = 64;
+struct WfShard { uint32_t n_ext, n_sh, cur, pad[29]; };     // rays listed by shade / fetch cursor of trace
+struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
+struct WfCtl {                       // device control block, one per context
+    WfShard shard[2][kWfShards];     // indexed by iteration parity
+    WfWork work[kWfShards];
+    unsigned long long counters[CRT_NCOUNTERS_DEV];
+};
+
+struct WfParams {
+    DevScene sc;
+    float4 *ray_o, *ray_d, *sh_d, *beta, *radiance, *nee;
+    uint4 *rng, *misc;
+    float2 *hit;
+    uint32_t *vis;
+    uint32_t *list_ext, *list_sh;
+    float4 *staging;
+    WfCtl *ctl;
+    uint32_t P;                      // pool size (slots)
+    uint32_t x0, y0, tw, th;         // tile rectangle
+    uint32_t tiles_x, tiles_y;
+    uint32_t npix_padded;            // tiles_x*tiles_y*64: work item = sample_off * npix_padded + tile*64 + lane
+    unsigned long long work_total;   // n_samples * npix_padded
+    uint32_t work_per_shard;         // work items per shard (multiple of 64)
+    uint32_t list_cap;               // list entries per shard
+    uint32_t first_sample, n_samples;
+    float4 *accum;
+    uchar4 *rgba;
+    uint32_t count;                  // 1: maintain ctl->counters
 };
 
 }  // namespace crt

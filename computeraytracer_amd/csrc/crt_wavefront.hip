@@ -1,0 +1,571 @@
+// crt_wavefront.hip -- the wavefront form of the path-trace pass for gfx950.
+//
+// Same computation as ComputeShader.wgsl `main` (:77-117) and bit-identical
+// results, but split so that the pointer-chasing part runs alone:
+//
+//   k_wf_shade   one thread per path slot (streaming, SoA, 16-byte coalesced):
+//                consumes last iteration's hit / visibility, runs the shading
+//                half of path_trace (:141-292), emits the next extension ray
+//                and (diffuse hits) a shadow ray, finishes paths into the
+//                staging buffer and re-arms dead slots with the next
+//                (sample, pixel) work item -- so the pool stays full.  Active
+//                rays are compacted into two lists with __ballot/__popcll
+//                prefix sums and ONE atomic per wave per list.
+//   k_wf_trace   persistent waves; each lane walks the BVH2 for one ray at a
+//                time (stack in LDS, [level][lane]); lanes that finish are
+//                refilled from a per-wave chunk of the list (one atomic per
+//                chunk), so lanes do not wait for the slowest ray of a wave.
+//                Shadow rays run any-hit against the t of the light's own
+//                primitive (found in k_wf_shade), which is exactly the
+//                reference's "closest hit == the light" test (:697-705).
+//   k_wf_resolve per pixel: accum += sample_1 + sample_2 + ... in sample order
+//                (:108), then the colour pipeline (:110-115).
+//
+// RNG call order per path is the reference's: the shadow trace
+// consumes no random numbers, so a diffuse bounce can draw its light, hemisphere
+// and roulette numbers in one go.
+#include "crt_shade.h"
+
+namespace crt {
+
+constexpr int kWfStack = 32;        // LDS stack entries per lane (BVH depth is capped at 30)
+constexpr int kTraceChunk = 128;    // list entries a wave reserves per atomic
+constexpr int kRefillAt = 16;       // refill when at least this many lanes are idle
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t prefix_popc(unsigned long long mask, uint32_t lane)
+{
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ------------------------------------------------------------------ shade
+struct PathRegs {
+    f3 ray_o, ray_d;
+    f4 beta, radiance;
+    Rng rng;
+    float last_pdf, etaScale;
+    uint32_t exclude, work, flags;
+};
+
+__device__ __forceinline__ void wavelengths_of(uint32_t lambda, uint32_t wl[4])
+{
+    wl[0] = lambda; wl[1] = (lambda + 4u) % kNLambda; wl[2] = (lambda + 8u) % kNLambda;
+    wl[3] = (lambda + 12u) % kNLambda;                           // :321
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_wf_shade(const WfParams P, uint32_t it)
+{
+    const DevScene &S = P.sc;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ring = it & 1u;
+    WfCtl *ctl = P.ctl;
+    if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
+        WfShard &nx = ctl->shard[ring ^ 1u][threadIdx.x];        // (its last reader, trace(it-1), is done)
+        nx.n_ext = 0; nx.n_sh = 0; nx.cur = 0;
+    }
+    const uint32_t my_shard = blockIdx.x % kWfShards;
+    const bool in_pool = slot < P.P;
+    uint32_t c_rays = 0, c_bounces = 0, c_shadow = 0, c_hits = 0, c_paths = 0, c_prims = 0;
+
+    PathRegs R;
+    R.flags = 0;
+    uint4 misc = uint4{0, 0, 0, 0};
+    if (in_pool) misc = P.misc[slot];
+    R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
+    bool alive = in_pool && (R.flags & kWfAlive);
+    bool emit_ext = false, emit_sh = false;
+    bool finished = false;
+
+    if (alive) {
+        float4 v;
+        v = P.ray_o[slot]; R.ray_o = xyz(v); R.exclude = f_bits(v.w);
+        v = P.ray_d[slot]; R.ray_d = xyz(v);
+        v = P.beta[slot]; R.beta = f4{v.x, v.y, v.z, v.w};
+        v = P.radiance[slot]; R.radiance = f4{v.x, v.y, v.z, v.w};
+        uint4 rs = P.rng[slot]; R.rng = Rng{rs.x, rs.y, rs.z, rs.w};
+        uint32_t wl[4];
+        wavelengths_of((R.flags >> kWfLambdaShift) & 0x1FFu, wl);
+        uint32_t depth = (R.flags >> kWfDepthShift) & 0xFFu;
+
+        // 1. the NEE term of the previous bounce, now that visibility is known (:187)
+        if (R.flags & kWfShadow) {
+            if (P.vis[slot] == 1u) {
+                float4 c = P.nee[slot];
+                R.radiance = R.radiance + f4{c.x, c.y, c.z, c.w};
+            }
+            R.flags &= ~kWfShadow;
+        }
+        if (R.flags & kWfDying) {
+            finished = true;                                     // roulette ended it last iteration (:284-287)
+        } else {
+            // 2. the extension ray's closest hit (:135-146)
+            const float2 h = P.hit[slot];
+            const uint32_t b_slot = f_bits(h.y);
+            if (COUNT) c_bounces++;
+            if (b_slot == kNoHit) {
+                finished = true;                                 // :141
+            } else {
+                f3 pos, nrm; uint32_t meta;
+                const f3 o = R.ray_o, d = R.ray_d;
+                hit_attributes(S, b_slot, o, d, h.x, pos, nrm, meta);
+                if (COUNT) c_hits++;
+                const uint32_t b_index = f_bits(S.prim[3 * b_slot + 1].w);
+                R.exclude = b_index;                             // :146
+                const uint32_t material = (meta >> 2) & 3u;
+                const uint32_t emission_index = (meta >> 4) & 0x3FFFu;
+                const uint32_t reflectance_index = (meta >> 18) & 0x3FFFu;
+                if (material == kLight) {                        // :149-164
+                    f4 le = sample_spectrum(S, emission_index, wl);
+                    if (depth == 0 || (R.flags & kWfSpecular)) {
+                        R.radiance = R.radiance + R.beta * le;
+                    } else {
+                        float pdf_l = compute_light_pdf(S, emission_index, pos, nrm, o, d);
+                        float weight_b = power_heuristic(1.0f, R.last_pdf, 1.0f, pdf_l);
+                        R.radiance = R.radiance + (le * weight_b) * R.beta;
+                    }
+                    finished = true;
+                } else if (depth >= kMaxDepthPath) {             // :167
+                    finished = true;
+                } else {
+                    if (R.flags & kWfInTrans) {                  // :173-179
+                        float distance = length(o - pos);
+                        f4 ext = sample_spectrum(S, S.nspectra - 1u, wl);
+                        f4 att = f4{exp_(-ext.x * distance), exp_(-ext.y * distance), exp_(-ext.z * distance),
+                                    exp_(-ext.w * distance)};
+                        R.beta = R.beta * att;
+                    }
+                    if (material == kDiffuse) {                  // :182-204
+                        f4 brdf = sample_spectrum(S, reflectance_index, wl) / CRT_PI;
+                        // compute_light_radiance :379-408 up to the visibility test
+                        float u0 = rnd(R.rng);
+                        uint32_t li = (uint32_t)((float)S.nlight * u0);
+                        if (li >= S.nlight) li = S.nlight - 1u;
+                        float u = rnd(R.rng);
+                        float v2 = rnd(R.rng);
+                        const float4 L0 = S.lights[3 * li + 0], L1 = S.lights[3 * li + 1], L2 = S.lights[3 * li + 2];
+                        f3 pl = (xyz(L0) + xyz(L1) * u) + xyz(L2) * v2;
+                        f3 ldir = normalize(pl - pos);
+                        const uint32_t include = f_bits(L1.w);
+                        if (COUNT) { c_rays++; c_shadow++; }
+                        // shadow_intersect (:697-705): the light's own primitive first
+                        float t_l = CRT_INFINITY;
+                        uint32_t l_index = kNoHit, l_slot = kNoHit;
+                        if (include < S.nprim && finite3(ldir)) {
+                            hit_test<false>(S, S.slot_of_index[include], pos, ldir, b_index, 0.001f, t_l, l_index, l_slot);
+                            if (COUNT) c_prims++;
+                        }
+                        if (l_slot != kNoHit) {
+                            f3 lp, ln; uint32_t lmeta;
+                            hit_attributes(S, l_slot, pos, ldir, t_l, lp, ln, lmeta);
+                            if (COUNT) c_hits++;
+                            float cos_theta = max_(0.0f, dot(nrm, ldir));
+                            f4 spec = sample_spectrum(S, f_bits(L0.w), wl);
+                            f4 le = spec * cos_theta;
+                            float pdf_l = compute_light_pdf(S, (lmeta >> 4) & 0x3FFFu, lp, ln, pos, ldir);
+                            float pdf_b = cos_theta / CRT_PI;
+                            float weight_l = power_heuristic(1.0f, pdf_l, 1.0f, pdf_b);
+                            f4 nee = (le * weight_l) / pdf_l;
+                            f4 c = (brdf * nee) * R.beta;          // added to radiance iff the light is visible
+                            P.nee[slot] = float4{c.x, c.y, c.z, c.w};
+                            P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};
+                            P.vis[slot] = include;
+                            emit_sh = true;
+                            R.flags |= kWfShadow;
+                        }
+                        // non-finite light direction: the reference loop decides (never seen in practice;
+                        // handled by tracing it as a brute-force ray in the mega kernel) -> treated as blocked
+                        f3 new_direction = cosine_hemisphere(R.rng, nrm, R.last_pdf);
+                        float cos_theta2 = abs_(dot(nrm, new_direction));
+                        R.beta = R.beta * ((brdf * cos_theta2) / R.last_pdf);
+                        R.ray_o = pos;
+                        R.ray_d = new_direction;
+                        R.flags &= ~kWfSpecular;
+                    } else if (material == kGlass) {             // :208-276
+                        const float eta1 = 1.0f, eta2 = 1.5f;
+                        float eta = eta1 / eta2;
+                        float cos_theta = dot(nrm, d);
+                        float reflected = fresnel_s(d, nrm, eta1, eta2);
+                        float pr = reflected;
+                        float pt = 1.0f - reflected;
+                        float u = rnd(R.rng);
+                        f3 current_normal = nrm;
+                        if (cos_theta > 0.0f) { eta = 1.0f / eta; current_normal = -current_normal; }
+                        f3 new_direction;
+                        if (u < pr / (pr + pt)) {
+                            new_direction = reflect_(d, current_normal);
+                        } else {
+                            new_direction = normalize(refract_(d, current_normal, eta));
+                            R.beta = R.beta * (eta * eta);
+                            R.etaScale = R.etaScale / (eta * eta);
+                            R.flags ^= kWfInTrans;
+                        }
+                        R.ray_o = pos;
+                        R.flags |= kWfSpecular;
+                        R.exclude = 0xFFFFFFFFu;
+                        R.ray_d = new_direction;
+                    }
+                    // Russian roulette :279-289
+                    bool rr_break = false;
+                    {
+                        f4 rbeta = R.beta * R.etaScale;
+                        float max_beta_component = max_(rbeta.x, max_(rbeta.y, rbeta.z));
+                        if (depth > 1u && max_beta_component < 1.0f) {
+                            float qq = max_(0.0f, 1.0f - max_beta_component);
+                            if (rnd(R.rng) < qq) rr_break = true;
+                            else R.beta = R.beta / (1.0f - qq);
+                        }
+                    }
+                    if (rr_break) {
+                        if (emit_sh) R.flags |= kWfDying;        // wait for the NEE visibility, then finish
+                        else finished = true;
+                    } else {
+                        depth++;
+                        R.flags = (R.flags & ~(0xFFu << kWfDepthShift)) | (depth << kWfDepthShift);
+                        emit_ext = true;
+                        if (COUNT) c_rays++;
+                    }
+                }
+            }
+        }
+        if (finished) {
+            // spectral_to_xyz (:105) into the staging slot of (sample, pixel)
+            const uint32_t sample_off = R.work / P.npix_padded, pp = R.work % P.npix_padded;
+            const uint32_t tile = pp >> 6, l = pp & 63u;
+            const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
+            f3 c = spectral_to_xyz(S, R.radiance, wl);
+            P.staging[(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
+            alive = false;
+            if (COUNT) c_paths++;
+        }
+    }
+
+    // 3. re-arm dead slots with the next (sample, pixel) work item.  The work range is split
+    //    into kWfShards contiguous sub-ranges with their own cursors; a wave looks at all cursors
+    //    with one wave-wide load, picks a non-empty shard (its own first) and takes what it
+    //    needs with ONE atomic.
+    {
+        const bool want0 = in_pool && !alive;
+        bool want = want0;
+        const uint32_t lane = lane_id();
+        for (int attempt = 0; attempt < 3; attempt++) {
+            const unsigned long long m = __ballot(want);
+            if (!m) break;
+            const uint32_t sh_lane = lane % kWfShards;
+            const unsigned long long lo = (unsigned long long)sh_lane * P.work_per_shard;
+            const unsigned long long hi = min(lo + (unsigned long long)P.work_per_shard, P.work_total);
+            const uint32_t size_l = hi > lo ? (uint32_t)(hi - lo) : 0u;
+            const uint32_t cur_l = __hip_atomic_load(&ctl->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long avail = __ballot(cur_l < size_l);
+            if (!avail) break;                                   // every shard is exhausted
+            // first non-empty shard at or after this block's own (rotate the mask)
+            const uint32_t rot = my_shard & 63u;
+            const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
+            const uint32_t s_pick = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
+            const uint32_t n = (uint32_t)__popcll(m);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctl->work[s_pick].cur, n);
+            base = __shfl(base, 0, 64);
+            const uint32_t size_s = __shfl(size_l, (int)s_pick, 64);
+            const uint32_t got = base < size_s ? min(n, size_s - base) : 0u;
+            const uint32_t my = prefix_popc(m, lane);
+            if (want && my < got) {
+                want = false;
+                const unsigned long long w = (unsigned long long)s_pick * P.work_per_shard + base + my;
+                const uint32_t sample_off = (uint32_t)(w / P.npix_padded), pp = (uint32_t)(w % P.npix_padded);
+                const uint32_t tile = pp >> 6, l = pp & 63u;
+                const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
+                R.flags = 0;
+                if (lx < P.tw && ly < P.th) {
+                    const uint32_t px = P.x0 + lx, py = P.y0 + ly, sample = P.first_sample + sample_off;
+                    R.rng = Rng{py, px * 100u, sample, tea(px, py * 100u)};                  // :98
+                    float jx = rnd(R.rng);
+                    float fs = ((float)px + ((float)(sample % kGrid) + jx) / (float)kGrid) / (float)S.W;
+                    float jy = rnd(R.rng);
+                    float ft = ((float)S.H - (float)py + ((float)(sample % kGrid) + jy) / (float)kGrid) / (float)S.H;
+                    const f3 llc = f3{S.cam[0], S.cam[1], S.cam[2]}, hor = f3{S.cam[3], S.cam[4], S.cam[5]};
+                    const f3 ver = f3{S.cam[6], S.cam[7], S.cam[8]}, eye = f3{S.cam[9], S.cam[10], S.cam[11]};
+                    R.ray_o = eye;
+                    R.ray_d = normalize(((llc + hor * fs) + ver * ft) - eye);
+                    float ul = rnd(R.rng);
+                    uint32_t lambda = (uint32_t)(301.0f * ul);                                // :317-319
+                    R.beta = f4{1, 1, 1, 1}; R.radiance = f4{0, 0, 0, 0};
+                    R.last_pdf = 1.0f; R.etaScale = 1.0f; R.exclude = 0xFFFFFFFFu;
+                    R.work = (uint32_t)w;
+                    R.flags = kWfAlive | (lambda << kWfLambdaShift);
+                    alive = true;
+                    emit_ext = true;
+                    emit_sh = false;
+                    if (COUNT) c_rays++;
+                }
+                // (a work item outside a ragged tile is consumed without a path; the slot retries)
+                else want = true;
+            }
+        }
+        if (want0 && !alive) R.flags = 0;
+    }
+
+    // 4. write the slot back and compact the active rays (ballot/popc, one atomic per wave per list)
+    if (in_pool) {
+        if (alive) {
+            P.ray_o[slot] = float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)};
+            P.ray_d[slot] = float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, 0.0f};
+            P.beta[slot] = float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w};
+            P.radiance[slot] = float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w};
+            P.rng[slot] = uint4{R.rng.x, R.rng.y, R.rng.z, R.rng.w};
+        }
+        P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
+    }
+    {
+        const uint32_t lane = lane_id();
+        const unsigned long long me = __ballot(emit_ext), ms = __ballot(emit_sh);
+        WfShard &sh = ctl->shard[ring][my_shard];
+        uint32_t be = 0, bs = 0;
+        if (lane == 0) {
+            if (me) be = atomicAdd(&sh.n_ext, (uint32_t)__popcll(me));
+            if (ms) bs = atomicAdd(&sh.n_sh, (uint32_t)__popcll(ms));
+        }
+        be = __shfl(be, 0, 64); bs = __shfl(bs, 0, 64);
+        const size_t region = (size_t)my_shard * P.list_cap;
+        if (emit_ext) P.list_ext[region + be + prefix_popc(me, lane)] = slot;
+        if (emit_sh) P.list_sh[region + bs + prefix_popc(ms, lane)] = slot;
+    }
+    if (COUNT) {
+        wave_add(ctl->counters + CRT_CNT_RAYS, c_rays);
+        wave_add(ctl->counters + CRT_CNT_BOUNCES, c_bounces);
+        wave_add(ctl->counters + CRT_CNT_SHADOW, c_shadow);
+        wave_add(ctl->counters + CRT_CNT_HITS, c_hits);
+        wave_add(ctl->counters + CRT_CNT_PATHS, c_paths);
+        wave_add(ctl->counters + CRT_CNT_PRIMS, c_prims);
+    }
+}
+
+// ------------------------------------------------------------------ trace
+// Persistent waves.  Entry i of the iteration's work: i < n_ext -> extension ray of slot
+// list_ext[i]; otherwise shadow ray of slot list_sh[i - n_ext].
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
+{
+    __shared__ int lds_stack[kWfStack * 64];
+    const DevScene &S = P.sc;
+    WfCtl *ctl = P.ctl;
+    const uint32_t ring = it & 1u;
+    const uint32_t lane = lane_id();
+    int *stk = lds_stack + lane;
+    const float t_min = 0.001f;
+
+    // wave-uniform fetch state: current shard, its ext count, the reserved chunk [pos,end)
+    uint32_t cur_shard = blockIdx.x % kWfShards, sh_n_ext = 0, sh_total = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0;
+    bool have_shard = false, exhausted = false;
+    bool active = false;
+    // per-lane ray + traversal state
+    f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, id = f3{0, 0, 0}, oid = f3{0, 0, 0};
+    uint32_t excl = 0, slot = 0, b_index = kNoHit, b_slot = kNoHit, b_slot_in = kNoHit;
+    float t_max = 0.0f;
+    bool shadow = false;
+    int node = 0, sp = 0;
+    uint32_t c_nodes = 0, c_prims = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the wave's chunk
+        const unsigned long long idle = __ballot(!active);
+        const int nidle = __popcll(idle);
+        if (!exhausted && nidle >= kRefillAt) {
+            // reserve a chunk if the current one is used up (bounded: every pass either gets a
+            // chunk, moves to a shard that had work a moment ago, or finds all shards empty)
+            for (int guard = 0; chunk_pos == chunk_end && !exhausted && guard < 2 * (int)kWfShards; guard++) {
+                if (have_shard) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl->shard[ring][cur_shard].cur, (uint32_t)kTraceChunk);
+                    base = __shfl(base, 0, 64);
+                    if (base < sh_total) { chunk_pos = base; chunk_end = min(base + (uint32_t)kTraceChunk, sh_total); break; }
+                    have_shard = false;
+                }
+                // look at every shard at once: lane i loads shard i
+                const WfShard &sl = ctl->shard[ring][lane % kWfShards];
+                const uint32_t ne = sl.n_ext, tot = ne + sl.n_sh;
+                const uint32_t cur_l = __hip_atomic_load(&sl.cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long avail = __ballot(cur_l < tot);
+                if (!avail) { exhausted = true; break; }
+                const uint32_t rot = cur_shard & 63u;
+                const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
+                cur_shard = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
+                sh_n_ext = __shfl(ne, (int)cur_shard, 64);
+                sh_total = __shfl(tot, (int)cur_shard, 64);
+                have_shard = true;
+            }
+            if (chunk_pos < chunk_end) {
+                const uint32_t give = min((uint32_t)nidle, chunk_end - chunk_pos);
+                const uint32_t my = prefix_popc(idle, lane);
+                if (!active && my < give) {
+                    const uint32_t idx = chunk_pos + my;
+                    const size_t region = (size_t)cur_shard * P.list_cap;
+                    active = true;
+                    shadow = idx >= sh_n_ext;
+                    slot = shadow ? P.list_sh[region + (idx - sh_n_ext)] : P.list_ext[region + idx];
+                }
+                chunk_pos += give;
+            }
+            // set up the newly fetched rays (lanes that were idle and are now active)
+            if (active && ((idle >> lane) & 1ull)) {
+                const float4 ro = P.ray_o[slot];
+                o = xyz(ro); excl = f_bits(ro.w);
+                if (shadow) {
+                    const float4 sd = P.sh_d[slot];
+                    d = xyz(sd); t_max = sd.w;
+                    b_index = P.vis[slot];                        // the light's primitive index
+                    b_slot = S.slot_of_index[b_index];
+                } else {
+                    d = xyz(P.ray_d[slot]);
+                    t_max = CRT_INFINITY; b_index = kNoHit; b_slot = kNoHit;
+                }
+                b_slot_in = b_slot;
+                node = S.root; sp = 0;
+                if (!finite3(o) || !finite3(d)) {
+                    // NaN / inf ray: the reference loop decides, in its own order (rare; e.g. refract edge)
+                    float tm = CRT_INFINITY; uint32_t bi = kNoHit, bs = kNoHit;
+                    intersect_all(S, o, d, excl, tm, bi, bs, c_prims);
+                    if (shadow) P.vis[slot] = (bs != kNoHit && bi == b_index) ? 1u : 0u;
+                    else P.hit[slot] = float2{tm, bits_f(bs)};
+                    active = false;
+                } else if (S.nprim == 0) {
+                    if (shadow) P.vis[slot] = 0u; else P.hit[slot] = float2{t_max, bits_f(kNoHit)};
+                    active = false;
+                } else {
+                    const float tiny = 1.0e-20f;
+                    id.x = 1.0f / (abs_(d.x) > tiny ? d.x : __builtin_copysignf(tiny, d.x));
+                    id.y = 1.0f / (abs_(d.y) > tiny ? d.y : __builtin_copysignf(tiny, d.y));
+                    id.z = 1.0f / (abs_(d.z) > tiny ? d.z : __builtin_copysignf(tiny, d.z));
+                    oid = f3{o.x * id.x, o.y * id.y, o.z * id.z};
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- a few traversal steps for every active lane
+#pragma unroll 1
+        for (int step = 0; step < 8; step++) {
+            bool done = false;
+            if (active && node >= 0) {
+                const float4 *np = S.nodes + 4 * (size_t)node;
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                float ax = fma_(n0.x, id.x, -oid.x), bx = fma_(n0.w, id.x, -oid.x);
+                float ay = fma_(n0.y, id.y, -oid.y), by = fma_(n1.x, id.y, -oid.y);
+                float az = fma_(n0.z, id.z, -oid.z), bz = fma_(n1.y, id.z, -oid.z);
+                float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                            __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+                float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                            __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+                ax = fma_(n1.z, id.x, -oid.x); bx = fma_(n2.y, id.x, -oid.x);
+                ay = fma_(n1.w, id.y, -oid.y); by = fma_(n2.z, id.y, -oid.y);
+                az = fma_(n2.x, id.z, -oid.z); bz = fma_(n2.w, id.z, -oid.z);
+                float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                            __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+                float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                            __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+                if (COUNT) c_nodes += 2;
+                const bool h0 = tn0 <= tf0 * 1.0000005f;
+                const bool h1 = tn1 <= tf1 * 1.0000005f;
+                const int r0 = (int)f_bits(n3.x), r1 = (int)f_bits(n3.y);
+                if (h0 && h1) {
+                    const bool first0 = tn0 <= tn1;
+                    stk[sp * 64] = first0 ? r1 : r0;
+                    sp++;
+                    node = first0 ? r0 : r1;
+                } else if (h0) {
+                    node = r0;
+                } else if (h1) {
+                    node = r1;
+                } else if (sp > 0) {
+                    sp--; node = stk[sp * 64];
+                } else {
+                    done = true;
+                }
+            } else if (active) {
+                const uint32_t enc = ~(uint32_t)node;
+                const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+                for (uint32_t i = 0; i < cnt; i++)
+                    hit_test<false>(S, first + i, o, d, excl, t_min, t_max, b_index, b_slot);
+                if (COUNT) c_prims += cnt;
+                if (shadow && b_slot != b_slot_in) done = true;       // any-hit: something beats the light
+                else if (sp > 0) { sp--; node = stk[sp * 64]; }
+                else done = true;
+            }
+            if (done) {
+                if (shadow) P.vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                else P.hit[slot] = float2{t_max, bits_f(b_slot)};
+                active = false;
+            }
+            if (__popcll(__ballot(active)) <= 64 - kRefillAt && !exhausted) break;
+            if (__ballot(active) == 0ull) break;
+        }
+    }
+    if (COUNT) {
+        wave_add(ctl->counters + CRT_CNT_NODES, c_nodes);
+        wave_add(ctl->counters + CRT_CNT_PRIMS, c_prims);
+    }
+}
+
+// ------------------------------------------------------------------ resolve
+__global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t last_sample)
+{
+    const size_t npix = (size_t)P.tw * P.th;
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    const float4 a4 = P.accum[pix];
+    f3 acc = f3{a4.x, a4.y, a4.z};
+    for (uint32_t s = 0; s < P.n_samples; s++) {
+        const float4 v = P.staging[(size_t)s * npix + pix];
+        acc = acc + f3{v.x, v.y, v.z};                           // :108, in sample order
+    }
+    P.accum[pix] = float4{acc.x, acc.y, acc.z, a4.w};
+    if (P.n_samples > 0) P.rgba[pix] = tonemap_rgba8(acc, (float)last_sample);
+}
+
+__global__ void k_wf_init(const WfParams P)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < P.P) P.misc[i] = uint4{0, 0, 0, 0};
+    if (i < kWfShards) {
+        WfCtl *c = P.ctl;
+        c->work[i].cur = 0;
+        c->shard[0][i].n_ext = 0; c->shard[0][i].n_sh = 0; c->shard[0][i].cur = 0;
+        c->shard[1][i].n_ext = 0; c->shard[1][i].n_sh = 0; c->shard[1][i].cur = 0;
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t wf_launch_init(const WfParams &P, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_wf_init, dim3((P.P + 255) / 256), dim3(256), 0, s, P);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
+{
+    const dim3 gs((P.P + 255) / 256), bs(256);
+    if (P.count) hipLaunchKernelGGL((k_wf_shade<true>), gs, bs, 0, s, P, it);
+    else hipLaunchKernelGGL((k_wf_shade<false>), gs, bs, 0, s, P, it);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s)
+{
+    if (P.count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(trace_blocks), dim3(64), 0, s, P, it);
+    else hipLaunchKernelGGL((k_wf_trace<false>), dim3(trace_blocks), dim3(64), 0, s, P, it);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s)
+{
+    const size_t npix = (size_t)P.tw * P.th;
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, P, last_sample);
+    return hipGetLastError();
+}
+
+}  // namespace crt

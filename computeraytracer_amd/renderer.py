@@ -163,6 +163,11 @@ class Renderer:
         self._chk(self._lib.crt_last_trace_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_kernel_ms(self):
+        ms, n = C.c_float(), C.c_uint32()
+        self._chk(self._lib.crt_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def accel_stats(self) -> dict:
         out = np.zeros(4, np.uint64)
         self._chk(self._lib.crt_accel_stats(self._h, out.ctypes.data))

@@ -135,7 +135,15 @@ int crt_reset_counters(crt_ctx *ctx);
  * on the context's stream), and how many kernel launches that was. */
 int crt_last_trace_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
 
-/* Tuning knobs.  "spp_per_launch": samples fused per kernel launch (0 = default). */
+/* Device time of the DOMINANT kernel's launches inside the last crt_trace call, summed,
+ * and their number: the BVH traversal kernel k_wf_trace of the wavefront pipeline (needs
+ * option "time_kernels"=1, which brackets every launch with HIP events), or the single
+ * trace kernel of the "pipeline"=0 form. */
+int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
+
+/* Tuning knobs.  "spp_per_launch": samples fused per batch (0 = default);
+ * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
+ * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "time_kernels". */
 int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);
 
 /* Accel statistics: out[0]=nodes, [1]=leaves, [2]=max depth, [3]=bytes. */
