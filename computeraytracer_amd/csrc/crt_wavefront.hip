@@ -28,7 +28,7 @@
 
 namespace crt {
 
-constexpr int kWfStack = 32;        // LDS stack entries per lane (BVH depth is capped at 30)
+constexpr int kWfStack = 32;        // LDS stack entries per lane (BVH depth is capped at 30 by the builder)
 constexpr int kTraceChunk = 128;    // list entries a wave reserves per atomic
 constexpr int kRefillAt = 16;       // refill when at least this many lanes are idle
 
@@ -36,6 +36,21 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t prefix_popc(unsigned long long mask, uint32_t lane)
 {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// The reference's own loop (:503-518) for a non-finite ray, out of line and taking only
+// values (a by-reference scene would force the kernel-argument struct into scratch).
+__device__ __noinline__ void resolve_nonfinite(const float4 *prim, const float4 *primD, const uint32_t *slot_of_index,
+                                               uint32_t nprim, float hit_pad, float ox, float oy, float oz, float dx,
+                                               float dy, float dz, uint32_t exclude, float2 *out)
+{
+    DevScene S{};
+    S.prim = prim; S.primD = primD; S.slot_of_index = slot_of_index; S.nprim = nprim; S.hit_pad = hit_pad;
+    float tm = CRT_INFINITY;
+    uint32_t bi = kNoHit, bs = kNoHit;
+    const f3 o = f3{ox, oy, oz}, d = f3{dx, dy, dz};
+    for (uint32_t i = 0; i < nprim; i++) hit_test<true>(S, slot_of_index[i], o, d, exclude, 0.001f, tm, bi, bs);
+    *out = float2{tm, bits_f(bs)};
 }
 
 // ------------------------------------------------------------------ shade
@@ -309,7 +324,17 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfParams P, uint32_t it)
     if (in_pool) {
         if (alive) {
             P.ray_o[slot] = float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)};
-            P.ray_d[slot] = float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, 0.0f};
+            // A non-finite ray (e.g. refract at the numerical edge of total reflection) is decided
+            // by the reference loop in its own order; do that here and flag the ray as resolved
+            // so the traversal kernel stays free of the fallback.
+            uint32_t resolved = 0u;
+            if (emit_ext && (!finite3(R.ray_o) || !finite3(R.ray_d))) {
+                resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, R.ray_o.x, R.ray_o.y, R.ray_o.z,
+                                  R.ray_d.x, R.ray_d.y, R.ray_d.z, R.exclude, &P.hit[slot]);
+                if (COUNT) c_prims += S.nprim;
+                resolved = 1u;
+            }
+            P.ray_d[slot] = float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)};
             P.beta[slot] = float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w};
             P.radiance[slot] = float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w};
             P.rng[slot] = uint4{R.rng.x, R.rng.y, R.rng.z, R.rng.w};
@@ -341,14 +366,64 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfParams P, uint32_t it)
 }
 
 // ------------------------------------------------------------------ trace
-// Persistent waves.  Entry i of the iteration's work: i < n_ext -> extension ray of slot
-// list_ext[i]; otherwise shadow ray of slot list_sh[i - n_ext].
+// Branch-free Moeller-Trumbore (same operations and order as hit_test's category 2): every
+// lane runs the whole test, the accept decision is one predicate, and only an accepted
+// candidate takes the (rare) bounding-box acceptance branch.  Early-outs would not save
+// anything under SIMT -- the wave runs until its last lane is through.
+__device__ __forceinline__ void tri_test(const float4 A, const float4 B, const float4 C, uint32_t slot, f3 o, f3 d,
+                                         uint32_t exclude, float t_min, float hit_pad, float &t_max,
+                                         uint32_t &b_index, uint32_t &b_slot)
+{
+    const uint32_t index = f_bits(B.w);
+    const f3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
+    const f3 pvec = cross(d, e2);
+    const float det = dot(e1, pvec);
+    const float inv = 1.0f / det;
+    const f3 tvec = o - v0;
+    const float u = dot(tvec, pvec) * inv;
+    const f3 qvec = cross(tvec, e1);
+    const float v = dot(d, qvec) * inv;
+    const float t = dot(e2, qvec) * inv;
+    const bool ok = (exclude != index) & (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) &
+                    beats<false>(t, t_min, t_max, index, b_index, b_slot);
+    if (ok) {
+        const f3 p = ray_at(o, d, t);
+        const f3 v1 = v0 + e1, v2 = v0 + e2;
+        const bool in = p.x >= min_(v0.x, min_(v1.x, v2.x)) - hit_pad && p.x <= max_(v0.x, max_(v1.x, v2.x)) + hit_pad &&
+                        p.y >= min_(v0.y, min_(v1.y, v2.y)) - hit_pad && p.y <= max_(v0.y, max_(v1.y, v2.y)) + hit_pad &&
+                        p.z >= min_(v0.z, min_(v1.z, v2.z)) - hit_pad && p.z <= max_(v0.z, max_(v1.z, v2.z)) + hit_pad;
+        if (in) { t_max = t; b_index = index; b_slot = slot; }
+    }
+}
+
+// Persistent waves.  A wave owns a chunk of one shard's ray list at a time; entry i of a shard:
+// i < n_ext -> extension ray of slot list_ext[i]; otherwise shadow ray of slot list_sh[i - n_ext].
+// Traversal is "while-while": a bounded run of inner-node steps (lanes that reach a leaf wait,
+// cheaply), then one leaf step for every lane that has one -- so the expensive primitive tests
+// run with most lanes on.
 template <bool COUNT>
 __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
 {
     __shared__ int lds_stack[kWfStack * 64];
-    const DevScene &S = P.sc;
     WfCtl *ctl = P.ctl;
+    // hot arrays as plain locals (keeps them in the global address space: global_load, not flat_load)
+    const float4 *__restrict__ nodes = P.sc.nodes;
+    const float4 *__restrict__ prim = P.sc.prim;
+    const float4 *__restrict__ primD = P.sc.primD;
+    const uint32_t *__restrict__ slot_of_index = P.sc.slot_of_index;
+    const float4 *__restrict__ g_ray_o = P.ray_o;
+    const float4 *__restrict__ g_ray_d = P.ray_d;
+    const float4 *__restrict__ g_sh_d = P.sh_d;
+    uint32_t *__restrict__ g_vis = P.vis;
+    float2 *__restrict__ g_hit = P.hit;
+    const uint32_t *__restrict__ list_ext = P.list_ext;
+    const uint32_t *__restrict__ list_sh = P.list_sh;
+    const float hit_pad = P.sc.hit_pad;
+    const int root = P.sc.root;
+    const uint32_t nprim = P.sc.nprim;
+    DevScene S = P.sc;                                         // for the rare patch / sphere tests
+    S.prim = prim; S.primD = primD;
+
     const uint32_t ring = it & 1u;
     const uint32_t lane = lane_id();
     int *stk = lds_stack + lane;
@@ -401,44 +476,33 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
                 if (!active && my < give) {
                     const uint32_t idx = chunk_pos + my;
                     const size_t region = (size_t)cur_shard * P.list_cap;
-                    active = true;
                     shadow = idx >= sh_n_ext;
-                    slot = shadow ? P.list_sh[region + (idx - sh_n_ext)] : P.list_ext[region + idx];
-                }
-                chunk_pos += give;
-            }
-            // set up the newly fetched rays (lanes that were idle and are now active)
-            if (active && ((idle >> lane) & 1ull)) {
-                const float4 ro = P.ray_o[slot];
-                o = xyz(ro); excl = f_bits(ro.w);
-                if (shadow) {
-                    const float4 sd = P.sh_d[slot];
-                    d = xyz(sd); t_max = sd.w;
-                    b_index = P.vis[slot];                        // the light's primitive index
-                    b_slot = S.slot_of_index[b_index];
-                } else {
-                    d = xyz(P.ray_d[slot]);
-                    t_max = CRT_INFINITY; b_index = kNoHit; b_slot = kNoHit;
-                }
-                b_slot_in = b_slot;
-                node = S.root; sp = 0;
-                if (!finite3(o) || !finite3(d)) {
-                    // NaN / inf ray: the reference loop decides, in its own order (rare; e.g. refract edge)
-                    float tm = CRT_INFINITY; uint32_t bi = kNoHit, bs = kNoHit;
-                    intersect_all(S, o, d, excl, tm, bi, bs, c_prims);
-                    if (shadow) P.vis[slot] = (bs != kNoHit && bi == b_index) ? 1u : 0u;
-                    else P.hit[slot] = float2{tm, bits_f(bs)};
-                    active = false;
-                } else if (S.nprim == 0) {
-                    if (shadow) P.vis[slot] = 0u; else P.hit[slot] = float2{t_max, bits_f(kNoHit)};
-                    active = false;
-                } else {
+                    slot = shadow ? list_sh[region + (idx - sh_n_ext)] : list_ext[region + idx];
+                    // set up the ray
+                    const float4 ro = g_ray_o[slot];
+                    o = xyz(ro); excl = f_bits(ro.w);
+                    active = true;
+                    if (shadow) {
+                        const float4 sd = g_sh_d[slot];
+                        d = xyz(sd); t_max = sd.w;
+                        b_index = g_vis[slot];                    // the light's primitive index
+                        b_slot = slot_of_index[b_index];
+                    } else {
+                        const float4 rd = g_ray_d[slot];
+                        d = xyz(rd);
+                        t_max = CRT_INFINITY; b_index = kNoHit; b_slot = kNoHit;
+                        if (f_bits(rd.w) != 0u) active = false;   // non-finite ray, already resolved by k_wf_shade
+                        else if (nprim == 0u) { g_hit[slot] = float2{t_max, bits_f(kNoHit)}; active = false; }
+                    }
+                    b_slot_in = b_slot;
+                    node = root; sp = 0;
                     const float tiny = 1.0e-20f;
                     id.x = 1.0f / (abs_(d.x) > tiny ? d.x : __builtin_copysignf(tiny, d.x));
                     id.y = 1.0f / (abs_(d.y) > tiny ? d.y : __builtin_copysignf(tiny, d.y));
                     id.z = 1.0f / (abs_(d.z) > tiny ? d.z : __builtin_copysignf(tiny, d.z));
                     oid = f3{o.x * id.x, o.y * id.y, o.z * id.z};
                 }
+                chunk_pos += give;
             }
         }
         if (__ballot(active) == 0ull) {
@@ -446,62 +510,78 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
             continue;
         }
 
-        // ---- a few traversal steps for every active lane
+        // ---- traversal bursts
 #pragma unroll 1
-        for (int step = 0; step < 8; step++) {
-            bool done = false;
-            if (active && node >= 0) {
-                const float4 *np = S.nodes + 4 * (size_t)node;
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                float ax = fma_(n0.x, id.x, -oid.x), bx = fma_(n0.w, id.x, -oid.x);
-                float ay = fma_(n0.y, id.y, -oid.y), by = fma_(n1.x, id.y, -oid.y);
-                float az = fma_(n0.z, id.z, -oid.z), bz = fma_(n1.y, id.z, -oid.z);
-                float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                                            __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
-                float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                                            __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
-                ax = fma_(n1.z, id.x, -oid.x); bx = fma_(n2.y, id.x, -oid.x);
-                ay = fma_(n1.w, id.y, -oid.y); by = fma_(n2.z, id.y, -oid.y);
-                az = fma_(n2.x, id.z, -oid.z); bz = fma_(n2.w, id.z, -oid.z);
-                float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                                            __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
-                float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                                            __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
-                if (COUNT) c_nodes += 2;
-                const bool h0 = tn0 <= tf0 * 1.0000005f;
-                const bool h1 = tn1 <= tf1 * 1.0000005f;
-                const int r0 = (int)f_bits(n3.x), r1 = (int)f_bits(n3.y);
-                if (h0 && h1) {
+        for (int burst = 0; burst < 4; burst++) {
+            // inner phase: up to kInnerRun box steps; a lane that has found a leaf waits here
+#pragma unroll 1
+            for (int k = 0; k < 6; k++) {
+                const bool inner = active && node >= 0;
+                if (__ballot(inner) == 0ull) break;
+                if (inner) {
+                    const float4 *np = nodes + 4 * (size_t)node;
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    float ax = fma_(n0.x, id.x, -oid.x), bx = fma_(n0.w, id.x, -oid.x);
+                    float ay = fma_(n0.y, id.y, -oid.y), by = fma_(n1.x, id.y, -oid.y);
+                    float az = fma_(n0.z, id.z, -oid.z), bz = fma_(n1.y, id.z, -oid.z);
+                    float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                                __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+                    float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                                __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+                    ax = fma_(n1.z, id.x, -oid.x); bx = fma_(n2.y, id.x, -oid.x);
+                    ay = fma_(n1.w, id.y, -oid.y); by = fma_(n2.z, id.y, -oid.y);
+                    az = fma_(n2.x, id.z, -oid.z); bz = fma_(n2.w, id.z, -oid.z);
+                    float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                                __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+                    float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                                __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+                    if (COUNT) c_nodes += 2;
+                    const bool h0 = tn0 <= tf0 * 1.0000005f;
+                    const bool h1 = tn1 <= tf1 * 1.0000005f;
+                    const int r0 = (int)f_bits(n3.x), r1 = (int)f_bits(n3.y);
                     const bool first0 = tn0 <= tn1;
-                    stk[sp * 64] = first0 ? r1 : r0;
-                    sp++;
-                    node = first0 ? r0 : r1;
-                } else if (h0) {
-                    node = r0;
-                } else if (h1) {
-                    node = r1;
-                } else if (sp > 0) {
-                    sp--; node = stk[sp * 64];
-                } else {
-                    done = true;
+                    if (h0 & h1) {
+                        stk[sp * 64] = first0 ? r1 : r0;
+                        sp++;
+                        node = first0 ? r0 : r1;
+                    } else if (h0 | h1) {
+                        node = h0 ? r0 : r1;
+                    } else if (sp > 0) {
+                        sp--; node = stk[sp * 64];
+                    } else {
+                        // stack empty: this ray is finished
+                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                        active = false;
+                    }
                 }
-            } else if (active) {
-                const uint32_t enc = ~(uint32_t)node;
-                const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-                for (uint32_t i = 0; i < cnt; i++)
-                    hit_test<false>(S, first + i, o, d, excl, t_min, t_max, b_index, b_slot);
-                if (COUNT) c_prims += cnt;
-                if (shadow && b_slot != b_slot_in) done = true;       // any-hit: something beats the light
-                else if (sp > 0) { sp--; node = stk[sp * 64]; }
-                else done = true;
             }
-            if (done) {
-                if (shadow) P.vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                else P.hit[slot] = float2{t_max, bits_f(b_slot)};
-                active = false;
+            // leaf phase: one leaf for every lane that has one
+            const bool leaf = active && node < 0;
+            if (__ballot(leaf) != 0ull) {
+                if (leaf) {
+                    const uint32_t enc = ~(uint32_t)node;
+                    const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+                    for (uint32_t i = 0; i < cnt; i++) {
+                        const uint32_t ps = first + i;
+                        const float4 A = prim[3 * (size_t)ps + 0], B = prim[3 * (size_t)ps + 1], C = prim[3 * (size_t)ps + 2];
+                        if ((f_bits(A.w) & 3u) == 2u) tri_test(A, B, C, ps, o, d, excl, t_min, hit_pad, t_max, b_index, b_slot);
+                        else hit_test<false>(S, ps, o, d, excl, t_min, t_max, b_index, b_slot);
+                    }
+                    if (COUNT) c_prims += cnt;
+                    bool done = false;
+                    if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
+                    else if (sp > 0) { sp--; node = stk[sp * 64]; }
+                    else done = true;
+                    if (done) {
+                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                        active = false;
+                    }
+                }
             }
-            if (__popcll(__ballot(active)) <= 64 - kRefillAt && !exhausted) break;
-            if (__ballot(active) == 0ull) break;
+            const int nact = __popcll(__ballot(active));
+            if (nact == 0 || (nact <= 64 - kRefillAt && !exhausted)) break;
         }
     }
     if (COUNT) {
