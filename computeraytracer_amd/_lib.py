@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt.so")
+LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt.so")   # CRT_LIB: tuning builds only
 
 NCOUNTERS = 8
 ACCEL_NONE, ACCEL_BVH2 = 0, 1

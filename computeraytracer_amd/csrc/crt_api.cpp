@@ -87,9 +87,14 @@ struct crt_ctx {
     bool have_scene = false;
     int accel_mode = -1;            // -1: not built
     Bvh bvh;
+    Bvh4 bvh4;
+    Bvh4Q bvh4q;
+    int quantize = 1;
 
     // device scene
-    DevBuf<float4> d_prim, d_primD, d_nodes, d_lights;
+    DevBuf<float4> d_prim, d_primD, d_nodes, d_nodes4, d_lights;
+    DevBuf<int> w_overflow;
+    DevBuf<uint4> d_nodes4q;
     DevBuf<uint32_t> d_slot_of_index;
     DevBuf<float> d_spectra, d_cie;
     DevScene sc{};
@@ -319,6 +324,23 @@ int upload_geometry(crt_ctx *c, int mode)
     c->sc.prim = c->d_prim.p;
     c->sc.primD = c->d_primD.p;
     c->sc.slot_of_index = c->d_slot_of_index.p;
+    c->bvh4 = Bvh4();
+    if (mode == CRT_ACCEL_BVH2 && n > 0) collapse_bvh4(c->bvh, c->bvh4);
+    size_t nn4 = c->bvh4.nodes.size() / 4;
+    HIPCHK(c, c->d_nodes4.alloc(std::max<size_t>(nn4, 8)));
+    if (nn4) HIPCHK(c, hipMemcpy(c->d_nodes4.p, c->bvh4.nodes.data(), nn4 * sizeof(float4), hipMemcpyHostToDevice));
+    c->sc.nodes4 = c->d_nodes4.p;
+    c->sc.root4 = c->bvh4.root;
+    c->bvh4q = Bvh4Q();
+    c->sc.nodes4q = nullptr;
+    if (c->quantize && c->bvh4.n_inner) quantize_bvh4(c->bvh4, c->bvh4q);
+    if (c->bvh4q.ok) {
+        size_t nq = c->bvh4q.nodes.size() / 4;
+        HIPCHK(c, c->d_nodes4q.alloc(nq));
+        HIPCHK(c, hipMemcpy(c->d_nodes4q.p, c->bvh4q.nodes.data(), nq * sizeof(uint4), hipMemcpyHostToDevice));
+        c->sc.nodes4q = c->d_nodes4q.p;
+        for (int a = 0; a < 3; a++) { c->sc.qbase[a] = c->bvh4q.base[a]; c->sc.qscale[a] = c->bvh4q.scale[a]; }
+    }
     c->sc.nodes = c->d_nodes.p;
     c->sc.root = c->bvh.root;
     c->sc.nprim = n;
@@ -348,6 +370,10 @@ int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
         hipDeviceProp_t prop;
         HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    {   // deep-stack overflow area: 64 levels beyond the LDS part for every resident traversal lane
+        const size_t lanes = (size_t)c->num_cu * c->wf_waves_per_cu * 64;
+        if (c->w_overflow.n < lanes * 64) HIPCHK(c, c->w_overflow.alloc(lanes * 64));
     }
     return CRT_OK;
 }
@@ -383,6 +409,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     W.first_sample = c->sample + 1; W.n_samples = n;
     W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
     W.count = c->counting ? 1u : 0u;
+    W.stack_overflow = c->w_overflow.p;
+    W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
     const uint32_t trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
 
     HIPCHK(c, wf_launch_init(W, c->stream));
@@ -478,7 +506,7 @@ void crt_destroy(crt_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_lights.release();
+    c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_lights.release(); c->w_overflow.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
@@ -794,7 +822,7 @@ int crt_accel_stats(crt_ctx *c, uint64_t out[4])
 {
     if (!c || !out) return CRT_EINVAL;
     out[0] = c->bvh.n_inner; out[1] = c->bvh.n_leaves; out[2] = c->bvh.max_depth;
-    out[3] = (uint64_t)c->bvh.n_inner * 64u + (uint64_t)c->prims.size() * 48u;
+    out[3] = (uint64_t)c->bvh.n_inner * 64u + (uint64_t)c->bvh4.n_inner * 128u + (uint64_t)c->prims.size() * 48u;
     return CRT_OK;
 }
 
@@ -803,6 +831,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!c || !name) return CRT_EINVAL;
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
+    if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "time_kernels")) { c->time_kernels = value != 0; return CRT_OK; }

@@ -182,4 +182,106 @@ void build_bvh2(const float *lo, const float *hi, uint32_t n, Bvh &out)
     out.nodes.resize((size_t)std::max<uint32_t>(out.n_inner, 1) * kNodeFloats);
 }
 
+
+namespace {
+struct Child4 { float lo[3], hi[3]; int32_t ref; };
+float area_of(const Child4 &c)
+{
+    float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+void children_of(const Bvh &b2, int32_t node, Child4 out[2])
+{
+    const float *nd = &b2.nodes[(size_t)node * kNodeFloats];
+    for (int c = 0; c < 2; c++) {
+        for (int a = 0; a < 3; a++) { out[c].lo[a] = nd[6 * c + a]; out[c].hi[a] = nd[6 * c + 3 + a]; }
+        std::memcpy(&out[c].ref, &nd[12 + c], 4);
+    }
+}
+int32_t collapse_rec(const Bvh &b2, int32_t ref2, Bvh4 &out, uint32_t depth)
+{
+    if (ref2 < 0) { out.max_depth = std::max(out.max_depth, depth); return ref2; }
+    Child4 ch[4];
+    int n = 2;
+    children_of(b2, ref2, ch);
+    while (n < 4) {                       // open the inner child with the largest surface
+        int best = -1; float ba = -1.0f;
+        for (int i = 0; i < n; i++) if (ch[i].ref >= 0) { float a = area_of(ch[i]); if (a > ba) { ba = a; best = i; } }
+        if (best < 0) break;
+        Child4 two[2];
+        children_of(b2, ch[best].ref, two);
+        ch[best] = two[0];
+        ch[n++] = two[1];
+    }
+    const uint32_t node = out.n_inner++;
+    if (out.nodes.size() < (size_t)(node + 1) * kNode4Floats) out.nodes.resize(std::max<size_t>(out.nodes.size() * 2, (size_t)(node + 1) * kNode4Floats));
+    int32_t refs[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) refs[i] = collapse_rec(b2, ch[i].ref, out, depth + 1);
+    float *nd = &out.nodes[(size_t)node * kNode4Floats];
+    for (int i = 0; i < 4; i++) {
+        for (int a = 0; a < 3; a++) {
+            nd[4 * a + i] = i < n ? ch[i].lo[a] : 3.0e38f;      // empty slot: a far-away point box,
+            nd[12 + 4 * a + i] = i < n ? ch[i].hi[a] : 3.0e38f;  // missed by every ray in the slab test
+        }
+        std::memcpy(&nd[24 + i], &refs[i], 4);
+        nd[28 + i] = 0.0f;
+    }
+    return (int32_t)node;
+}
+}  // namespace
+
+void collapse_bvh4(const Bvh &b2, Bvh4 &out)
+{
+    out = Bvh4();
+    out.nodes.assign((size_t)std::max<uint32_t>(b2.n_inner / 2 + 1, 1) * kNode4Floats, 0.0f);
+    out.root = collapse_rec(b2, b2.root, out, 0);
+    out.nodes.resize((size_t)std::max<uint32_t>(out.n_inner, 1) * kNode4Floats);
+}
+
+
+void quantize_bvh4(const Bvh4 &b4, Bvh4Q &out)
+{
+    out = Bvh4Q();
+    if (b4.n_inner == 0) return;
+    float glo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, ghi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (uint32_t n = 0; n < b4.n_inner; n++) {
+        const float *nd = &b4.nodes[(size_t)n * kNode4Floats];
+        for (int i = 0; i < 4; i++) {
+            if (nd[i] >= 3.0e38f) continue;                         // empty slot
+            for (int a = 0; a < 3; a++) {
+                float l = nd[4 * a + i], h = nd[12 + 4 * a + i];
+                if (!(l > -1.0e30f) || !(h < 1.0e30f)) return;      // unbounded primitive: not quantisable
+                glo[a] = std::min(glo[a], l); ghi[a] = std::max(ghi[a], h);
+            }
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        float ext = std::max(ghi[a] - glo[a], 1.0e-3f);
+        float mag = std::max(std::fabs(glo[a]), std::fabs(ghi[a]));
+        if (mag > 16.0f * ext) return;                              // too far from the origin for the slack
+        out.base[a] = glo[a];
+        out.scale[a] = ext / 65533.0f;
+    }
+    out.nodes.resize((size_t)b4.n_inner * 16);
+    for (uint32_t n = 0; n < b4.n_inner; n++) {
+        const float *nd = &b4.nodes[(size_t)n * kNode4Floats];
+        uint16_t q[24];
+        for (int i = 0; i < 4; i++) {
+            const bool empty = nd[i] >= 3.0e38f;
+            for (int a = 0; a < 3; a++) {
+                if (empty) { q[4 * a + i] = 65535; q[12 + 4 * a + i] = 0; continue; }
+                double l = ((double)nd[4 * a + i] - out.base[a]) / out.scale[a];
+                double h = ((double)nd[12 + 4 * a + i] - out.base[a]) / out.scale[a];
+                long ql = (long)std::floor(l) - 1, qh = (long)std::ceil(h) + 1;
+                q[4 * a + i] = (uint16_t)std::min<long>(std::max<long>(ql, 0), 65535);
+                q[12 + 4 * a + i] = (uint16_t)std::min<long>(std::max<long>(qh, 0), 65535);
+            }
+        }
+        uint32_t *o = &out.nodes[(size_t)n * 16];
+        for (int k = 0; k < 12; k++) o[k] = (uint32_t)q[2 * k] | ((uint32_t)q[2 * k + 1] << 16);
+        std::memcpy(&o[12], &nd[24], 16);
+    }
+    out.ok = true;
+}
+
 }  // namespace crt

@@ -23,4 +23,30 @@ struct Bvh {
 // lo/hi: n x 3 floats, already padded conservatively by the caller.
 void build_bvh2(const float *lo, const float *hi, uint32_t n, Bvh &out);
 
+// 4-wide form of the same tree for the wavefront traversal kernel: one 128-byte line per
+// node (random gathers cost per REQUEST on gfx950, not per byte -- see DESIGN.md 5.1):
+//   floats [0..3] lo.x of children 0..3, [4..7] lo.y, [8..11] lo.z, [12..15] hi.x, [16..19] hi.y,
+//   [20..23] hi.z, [24..27] child refs (same encoding as Bvh), [28..31] unused.
+// Empty child slots hold a far-away point box (lo = hi = 3e38, missed by every ray) and ref 0.
+constexpr int kNode4Floats = 32;
+struct Bvh4 {
+    std::vector<float> nodes;
+    int32_t root = -1;
+    uint32_t n_inner = 0, max_depth = 0;
+};
+void collapse_bvh4(const Bvh &b2, Bvh4 &out);
+
+// Quantised form of Bvh4: 64 bytes per node.  Box planes are 16-bit grid coordinates over the
+// scene bounds, rounded outward with one extra grid unit of slack (culling stays conservative):
+//   u16 lo.x[4] lo.y[4] | lo.z[4] hi.x[4] | hi.y[4] hi.z[4] | i32 refs[4]      (4 x 16 B)
+// plane = base[axis] + q * scale[axis].  Empty slots: lo = 65535, hi = 0 (never hit).
+// `ok` is false when the scene cannot be quantised safely (unbounded primitives, or bounds
+// so far from the origin that f32 rounding would exceed the slack); use Bvh4 then.
+struct Bvh4Q {
+    std::vector<uint32_t> nodes;   // 16 dwords per node
+    float base[3] = {0, 0, 0}, scale[3] = {1, 1, 1};
+    bool ok = false;
+};
+void quantize_bvh4(const Bvh4 &b4, Bvh4Q &out);
+
 }  // namespace crt

@@ -32,16 +32,20 @@ struct DevScene {
     const float4 *primD;
     const uint32_t *slot_of_index;
     const float4 *nodes;
+    const float4 *nodes4;       // 8 x float4 per 4-wide node (128 B)
+    const uint4 *nodes4q;       // 4 x uint4 per quantised 4-wide node (64 B), or null
     const float *spectra;
     const float *cie;
     const float4 *lights;
     uint32_t nprim;
     int32_t root;
+    int32_t root4;
     uint32_t nspectra;
     uint32_t nlight;
     float hit_pad;
     float inv_nlight;      // 1.0f / f32(nlight)
     uint32_t W, H;         // full image
+    float qbase[3], qscale[3];  // plane = qbase + q * qscale (quantised nodes)
     float cam[12];         // llc, horizontal, vertical, eye  (ComputeShader.wgsl:470-487 hoisted)
 };
 
@@ -106,6 +110,8 @@ struct WfParams {
     float4 *accum;
     uchar4 *rgba;
     uint32_t count;                  // 1: maintain ctl->counters
+    int *stack_overflow;             // [level - kWfStack][global lane], for stacks deeper than the LDS part
+    uint32_t overflow_lanes;
 };
 
 }  // namespace crt

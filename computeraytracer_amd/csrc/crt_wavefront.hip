@@ -28,9 +28,27 @@
 
 namespace crt {
 
-constexpr int kWfStack = 32;        // LDS stack entries per lane (BVH depth is capped at 30 by the builder)
-constexpr int kTraceChunk = 128;    // list entries a wave reserves per atomic
-constexpr int kRefillAt = 16;       // refill when at least this many lanes are idle
+#ifndef CRT_WF_STACK
+#define CRT_WF_STACK 32
+#endif
+#ifndef CRT_WF_REFILL
+#define CRT_WF_REFILL 16
+#endif
+#ifndef CRT_WF_INNER_RUN
+#define CRT_WF_INNER_RUN 6
+#endif
+#ifndef CRT_WF_BURSTS
+#define CRT_WF_BURSTS 4
+#endif
+#ifndef CRT_WF_BVH4
+#define CRT_WF_BVH4 1
+#endif
+#ifndef CRT_WF_MIN_WAVES
+#define CRT_WF_MIN_WAVES 1
+#endif
+constexpr int kWfStack = CRT_WF_STACK;      // LDS stack entries per lane (BVH depth is capped by the builder)
+constexpr int kTraceChunk = 128;            // list entries a wave reserves per atomic
+constexpr int kRefillAt = CRT_WF_REFILL;    // refill when at least this many lanes are idle
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t prefix_popc(unsigned long long mask, uint32_t lane)
@@ -401,13 +419,15 @@ __device__ __forceinline__ void tri_test(const float4 A, const float4 B, const f
 // Traversal is "while-while": a bounded run of inner-node steps (lanes that reach a leaf wait,
 // cheaply), then one leaf step for every lane that has one -- so the expensive primitive tests
 // run with most lanes on.
-template <bool COUNT>
-__global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
+template <bool COUNT, bool QUANT>
+__global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParams P, uint32_t it)
 {
     __shared__ int lds_stack[kWfStack * 64];
     WfCtl *ctl = P.ctl;
     // hot arrays as plain locals (keeps them in the global address space: global_load, not flat_load)
-    const float4 *__restrict__ nodes = P.sc.nodes;
+    const float4 *__restrict__ nodes = CRT_WF_BVH4 ? P.sc.nodes4 : P.sc.nodes;
+    const uint4 *__restrict__ nodesq = P.sc.nodes4q;
+    const f3 qscale = f3{P.sc.qscale[0], P.sc.qscale[1], P.sc.qscale[2]}, qbase = f3{P.sc.qbase[0], P.sc.qbase[1], P.sc.qbase[2]};
     const float4 *__restrict__ prim = P.sc.prim;
     const float4 *__restrict__ primD = P.sc.primD;
     const uint32_t *__restrict__ slot_of_index = P.sc.slot_of_index;
@@ -419,7 +439,9 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
     const uint32_t *__restrict__ list_ext = P.list_ext;
     const uint32_t *__restrict__ list_sh = P.list_sh;
     const float hit_pad = P.sc.hit_pad;
-    const int root = P.sc.root;
+    const int root = CRT_WF_BVH4 ? P.sc.root4 : P.sc.root;
+    int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
+    const size_t ovl = P.overflow_lanes;
     const uint32_t nprim = P.sc.nprim;
     DevScene S = P.sc;                                         // for the rare patch / sphere tests
     S.prim = prim; S.primD = primD;
@@ -440,6 +462,7 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
     float t_max = 0.0f;
     bool shadow = false;
     int node = 0, sp = 0;
+    int nx = 0, ny = 0, nz = 0;                      // 0: lo plane is the near one on that axis, 3: hi plane
     uint32_t c_nodes = 0, c_prims = 0;
 
     for (;;) {
@@ -501,6 +524,12 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
                     id.y = 1.0f / (abs_(d.y) > tiny ? d.y : __builtin_copysignf(tiny, d.y));
                     id.z = 1.0f / (abs_(d.z) > tiny ? d.z : __builtin_copysignf(tiny, d.z));
                     oid = f3{o.x * id.x, o.y * id.y, o.z * id.z};
+                    nx = id.x >= 0.0f ? 0 : 3; ny = id.y >= 0.0f ? 0 : 3; nz = id.z >= 0.0f ? 0 : 3;
+                    if (QUANT) {
+                        // plane = qbase + q*qscale  =>  t = q*(qscale*id) + (qbase*id - o*id): one fma per plane
+                        oid = f3{fma_(qbase.x, id.x, -oid.x), fma_(qbase.y, id.y, -oid.y), fma_(qbase.z, id.z, -oid.z)};
+                        id = f3{qscale.x * id.x, qscale.y * id.y, qscale.z * id.z};
+                    }
                 }
                 chunk_pos += give;
             }
@@ -512,13 +541,80 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
 
         // ---- traversal bursts
 #pragma unroll 1
-        for (int burst = 0; burst < 4; burst++) {
+        for (int burst = 0; burst < CRT_WF_BURSTS; burst++) {
             // inner phase: up to kInnerRun box steps; a lane that has found a leaf waits here
 #pragma unroll 1
-            for (int k = 0; k < 6; k++) {
+            for (int k = 0; k < CRT_WF_INNER_RUN; k++) {
                 const bool inner = active && node >= 0;
                 if (__ballot(inner) == 0ull) break;
                 if (inner) {
+#if CRT_WF_BVH4
+                  float k0, k1, k2, k3;
+                  int r0, r1, r2, r3;
+                  if (QUANT) {
+                    // one 64-byte node: 16-bit plane coordinates, near / far plane picked by the ray's signs
+                    const uint4 *nq = nodesq + 4 * (size_t)node;
+                    const uint4 Q0 = nq[0], Q1 = nq[1], Q2 = nq[2], Q3 = nq[3];
+                    const bool gx = nx != 0, gy = ny != 0, gz = nz != 0;
+                    const uint32_t nxa = gx ? Q1.z : Q0.x, nxb = gx ? Q1.w : Q0.y, fxa = gx ? Q0.x : Q1.z, fxb = gx ? Q0.y : Q1.w;
+                    const uint32_t nya = gy ? Q2.x : Q0.z, nyb = gy ? Q2.y : Q0.w, fya = gy ? Q0.z : Q2.x, fyb = gy ? Q0.w : Q2.y;
+                    const uint32_t nza = gz ? Q2.z : Q1.x, nzb = gz ? Q2.w : Q1.y, fza = gz ? Q1.x : Q2.z, fzb = gz ? Q1.y : Q2.w;
+#define CRT_QBOX(K, NXQ, NYQ, NZQ, FXQ, FYQ, FZQ) { \
+                        const float tn_ = __builtin_fmaxf(__builtin_fmaxf(fma_((float)(NXQ), id.x, oid.x), fma_((float)(NYQ), id.y, oid.y)), \
+                                                          __builtin_fmaxf(fma_((float)(NZQ), id.z, oid.z), t_min)); \
+                        const float tf_ = __builtin_fminf(__builtin_fminf(fma_((float)(FXQ), id.x, oid.x), fma_((float)(FYQ), id.y, oid.y)), \
+                                                          __builtin_fminf(fma_((float)(FZQ), id.z, oid.z), t_max)); \
+                        K = (tn_ <= tf_ * 1.0000005f) ? tn_ : 3.0e38f; }
+                    CRT_QBOX(k0, nxa & 0xFFFFu, nya & 0xFFFFu, nza & 0xFFFFu, fxa & 0xFFFFu, fya & 0xFFFFu, fza & 0xFFFFu)
+                    CRT_QBOX(k1, nxa >> 16, nya >> 16, nza >> 16, fxa >> 16, fya >> 16, fza >> 16)
+                    CRT_QBOX(k2, nxb & 0xFFFFu, nyb & 0xFFFFu, nzb & 0xFFFFu, fxb & 0xFFFFu, fyb & 0xFFFFu, fzb & 0xFFFFu)
+                    CRT_QBOX(k3, nxb >> 16, nyb >> 16, nzb >> 16, fxb >> 16, fyb >> 16, fzb >> 16)
+#undef CRT_QBOX
+                    r0 = (int)Q3.x; r1 = (int)Q3.y; r2 = (int)Q3.z; r3 = (int)Q3.w;
+                  } else {
+                    // one 128-byte node: boxes of 4 children as SoA planes lo.x lo.y lo.z hi.x hi.y hi.z.
+                    // The ray's direction signs pick the near / far plane per axis (no min/max per box).
+                    const float4 *np = nodes + 8 * (size_t)node;
+                    const float4 NX = np[nx], NY = np[1 + ny], NZ = np[2 + nz];
+                    const float4 FX = np[3 - nx], FY = np[4 - ny], FZ = np[5 - nz];
+                    const float4 RF = np[6];
+                    {
+                        float tn, tf;
+                        tn = __builtin_fmaxf(__builtin_fmaxf(fma_(NX.x, id.x, -oid.x), fma_(NY.x, id.y, -oid.y)), __builtin_fmaxf(fma_(NZ.x, id.z, -oid.z), t_min));
+                        tf = __builtin_fminf(__builtin_fminf(fma_(FX.x, id.x, -oid.x), fma_(FY.x, id.y, -oid.y)), __builtin_fminf(fma_(FZ.x, id.z, -oid.z), t_max));
+                        k0 = (tn <= tf * 1.0000005f) ? tn : 3.0e38f;
+                        tn = __builtin_fmaxf(__builtin_fmaxf(fma_(NX.y, id.x, -oid.x), fma_(NY.y, id.y, -oid.y)), __builtin_fmaxf(fma_(NZ.y, id.z, -oid.z), t_min));
+                        tf = __builtin_fminf(__builtin_fminf(fma_(FX.y, id.x, -oid.x), fma_(FY.y, id.y, -oid.y)), __builtin_fminf(fma_(FZ.y, id.z, -oid.z), t_max));
+                        k1 = (tn <= tf * 1.0000005f) ? tn : 3.0e38f;
+                        tn = __builtin_fmaxf(__builtin_fmaxf(fma_(NX.z, id.x, -oid.x), fma_(NY.z, id.y, -oid.y)), __builtin_fmaxf(fma_(NZ.z, id.z, -oid.z), t_min));
+                        tf = __builtin_fminf(__builtin_fminf(fma_(FX.z, id.x, -oid.x), fma_(FY.z, id.y, -oid.y)), __builtin_fminf(fma_(FZ.z, id.z, -oid.z), t_max));
+                        k2 = (tn <= tf * 1.0000005f) ? tn : 3.0e38f;
+                        tn = __builtin_fmaxf(__builtin_fmaxf(fma_(NX.w, id.x, -oid.x), fma_(NY.w, id.y, -oid.y)), __builtin_fmaxf(fma_(NZ.w, id.z, -oid.z), t_min));
+                        tf = __builtin_fminf(__builtin_fminf(fma_(FX.w, id.x, -oid.x), fma_(FY.w, id.y, -oid.y)), __builtin_fminf(fma_(FZ.w, id.z, -oid.z), t_max));
+                        k3 = (tn <= tf * 1.0000005f) ? tn : 3.0e38f;
+                    }
+                    r0 = (int)f_bits(RF.x); r1 = (int)f_bits(RF.y); r2 = (int)f_bits(RF.z); r3 = (int)f_bits(RF.w);
+                  }
+                    if (COUNT) c_nodes += 4;
+                    // sort the four (key, ref) pairs by entry distance: 5 compare-exchanges
+#define CRT_CAS(ka, ra, kb, rb) { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; kb = sw_ ? ka : kb; ka = tk_; \
+                                  const int tr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = tr_; }
+                    CRT_CAS(k0, r0, k1, r1) CRT_CAS(k2, r2, k3, r3) CRT_CAS(k0, r0, k2, r2) CRT_CAS(k1, r1, k3, r3) CRT_CAS(k1, r1, k2, r2)
+#undef CRT_CAS
+                    if (k0 < 3.0e38f) {
+                        // descend into the nearest; the others wait on the stack, farthest pushed first
+                        if (k3 < 3.0e38f) { if (sp < kWfStack) stk[sp * 64] = r3; else ovf[(size_t)(sp - kWfStack) * ovl] = r3; sp++; }
+                        if (k2 < 3.0e38f) { if (sp < kWfStack) stk[sp * 64] = r2; else ovf[(size_t)(sp - kWfStack) * ovl] = r2; sp++; }
+                        if (k1 < 3.0e38f) { if (sp < kWfStack) stk[sp * 64] = r1; else ovf[(size_t)(sp - kWfStack) * ovl] = r1; sp++; }
+                        node = r0;
+                    } else if (sp > 0) {
+                        sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
+                    } else {
+                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                        active = false;
+                    }
+#else
                     const float4 *np = nodes + 4 * (size_t)node;
                     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                     float ax = fma_(n0.x, id.x, -oid.x), bx = fma_(n0.w, id.x, -oid.x);
@@ -554,6 +650,7 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
                         else g_hit[slot] = float2{t_max, bits_f(b_slot)};
                         active = false;
                     }
+#endif
                 }
             }
             // leaf phase: one leaf for every lane that has one
@@ -571,7 +668,7 @@ __global__ __launch_bounds__(64) void k_wf_trace(const WfParams P, uint32_t it)
                     if (COUNT) c_prims += cnt;
                     bool done = false;
                     if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
-                    else if (sp > 0) { sp--; node = stk[sp * 64]; }
+                    else if (sp > 0) { sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl]; }
                     else done = true;
                     if (done) {
                         if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
@@ -635,8 +732,10 @@ hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
 
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s)
 {
-    if (P.count) hipLaunchKernelGGL((k_wf_trace<true>), dim3(trace_blocks), dim3(64), 0, s, P, it);
-    else hipLaunchKernelGGL((k_wf_trace<false>), dim3(trace_blocks), dim3(64), 0, s, P, it);
+    const dim3 g(trace_blocks), b(64);
+    const bool q = CRT_WF_BVH4 && P.sc.nodes4q != nullptr;
+    if (P.count) { if (q) hipLaunchKernelGGL((k_wf_trace<true, true>), g, b, 0, s, P, it); else hipLaunchKernelGGL((k_wf_trace<true, false>), g, b, 0, s, P, it); }
+    else { if (q) hipLaunchKernelGGL((k_wf_trace<false, true>), g, b, 0, s, P, it); else hipLaunchKernelGGL((k_wf_trace<false, false>), g, b, 0, s, P, it); }
     return hipGetLastError();
 }
 
