@@ -312,9 +312,9 @@ static napi_value js_accel_stats(napi_env env, napi_callback_info info)
     ARGS(1)
     crt_ctx *ctx = get_ctx(env, argv[0]);
     if (!ctx) return NULL;
-    uint64_t c[4];
+    uint64_t c[8];
     CRT_CHECK(env, ctx, "crt_accel_stats", crt_accel_stats(ctx, c));
-    return u64_array(env, c, 4);
+    return u64_array(env, c, 8);
 }
 
 static napi_value js_last_trace_ms(napi_env env, napi_callback_info info)

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64, help="samples per step (BASELINE config 3: 64)")
     ap.add_argument("--soup-tris", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-crop", default="128x72", help="oracle sample: centre crop WxH at 1 spp")
+    ap.add_argument("--cpu-crop", default="256x144", help="oracle sample: centre crop WxH at 1 spp")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,6 +67,7 @@ def main():
 
     r = Renderer(local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.set_option("time_kernels", 1)     # HIP events around every launch of the traversal kernel
     r.upload(ps)
     sf = StripFrame(W, H, world, rank, dev)
     y0, y1 = sf.y0, sf.y1
@@ -91,13 +92,14 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches, total_ms = 0.0, 0, 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        ms, nl = r.last_trace_ms()         # HIP events on the launch stream (waits for this step's kernels)
-        kernel_ms += ms
+        ms, nl = r.last_kernel_ms()        # HIP events on the launch stream around the k_wf_trace launches
+        kernel_ms += ms                    # (waits for this step's kernels)
         launches += nl
+        total_ms += r.last_trace_ms()[0]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -124,14 +126,17 @@ def main():
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
-        # roofline of the trace kernel on THIS rank: algorithmic bytes per launch
-        # over the average launch duration measured with HIP events inside the timed region.
+        # Roofline of the dominant kernel (k_wf_trace, the BVH walk) on THIS rank: algorithmic bytes
+        # (SURVEY.md 8d with this build's record sizes: node bytes per child box tested, 48 B per
+        # primitive tested, 16 B per closest-hit attribute fetch, 36 B per pixel-sample of
+        # framebuffer traffic) over the summed HIP-event durations of its launches in the timed region.
+        st = r.accel_stats()
         m_rays, m_nodes, m_prims, m_hits, m_paths, _ = [float(v) for v in mine.tolist()]
-        px_launches = float((y1 - y0) * W) * launches
-        alg_bytes = 32.0 * m_nodes + 48.0 * m_prims + 16.0 * m_hits + 36.0 * px_launches
+        alg_bytes = st["bytes_per_box"] * m_nodes + 48.0 * m_prims + 16.0 * m_hits + 36.0 * m_paths
         per_launch = alg_bytes / max(launches, 1)
         avg_ms = kernel_ms / max(launches, 1)
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        whole_pass = alg_bytes / (total_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/sec (+ HBM GB/s vs peak), 1080p 250k-tri scene, 1/2/4/8 MI355X",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -141,14 +146,18 @@ def main():
                                    f"{args.spp} spp per step (BASELINE config 3)" if args.scene == "atrium250k" else
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
                        "partition": f"{world} horizontal strip(s), scene replicated, all_gather of strips per step",
-                       "accel": "BVH2 binned SAH (host build %.2f s)" % t_build},
+                       "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s)" % t_build},
             "mpaths_per_s": round(paths / elapsed / 1e6, 3),
             "rays_per_path": round(rays / max(paths, 1), 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "k_trace", "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                         "kernel": "k_wf_trace", "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": round(per_launch),
-                         "bytes_per_ray": round(alg_bytes / max(m_rays, 1), 1)},
+                         "bytes_per_ray": round(alg_bytes / max(m_rays, 1), 1),
+                         "node_bytes_per_box": st["bytes_per_box"], "node_width": st["width"],
+                         "boxes_per_ray": round(m_nodes / max(m_rays, 1), 2), "prims_per_ray": round(m_prims / max(m_rays, 1), 2),
+                         "kernel_share_of_pass": round(kernel_ms / max(total_ms, 1e-9), 3),
+                         "whole_pass_GBs": round(whole_pass, 1), "whole_pass_frac": round(whole_pass / HBM_PEAK_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ps, args)
@@ -167,7 +176,7 @@ def cpu_baseline(ps, args):
     W, H = ps.width, ps.height
     x0, y0 = (W - cw) // 2, (H - ch) // 2 + H // 8
     sc = orc.Scene.from_packed(ps)
-    cores = os.cpu_count() or 1
+    cores = orc.max_threads()           # the OpenMP threads the oracle actually runs on
     t0 = time.perf_counter()
     _, _, cnt = sc.render(1, rect=(x0, y0, x0 + cw, y0 + ch))
     dt = time.perf_counter() - t0

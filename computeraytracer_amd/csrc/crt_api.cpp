@@ -818,9 +818,14 @@ int crt_last_kernel_ms(crt_ctx *c, float *ms, uint32_t *launches)
     return CRT_OK;
 }
 
-int crt_accel_stats(crt_ctx *c, uint64_t out[4])
+int crt_accel_stats(crt_ctx *c, uint64_t out[8])
 {
     if (!c || !out) return CRT_EINVAL;
+    const bool wide = c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2 && c->bvh4.n_inner > 0;
+    out[4] = wide ? (c->bvh4q.ok ? 16 : 32) : 32;      // bytes of node data per child box tested
+    out[5] = wide ? 4 : 2;                              // node width used by crt_trace
+    out[6] = wide ? c->bvh4.n_inner : c->bvh.n_inner;   // inner nodes of that tree
+    out[7] = 0;
     out[0] = c->bvh.n_inner; out[1] = c->bvh.n_leaves; out[2] = c->bvh.max_depth;
     out[3] = (uint64_t)c->bvh.n_inner * 64u + (uint64_t)c->bvh4.n_inner * 128u + (uint64_t)c->prims.size() * 48u;
     return CRT_OK;

@@ -169,9 +169,10 @@ class Renderer:
         return ms.value, n.value
 
     def accel_stats(self) -> dict:
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(8, np.uint64)
         self._chk(self._lib.crt_accel_stats(self._h, out.ctypes.data))
-        return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), bytes=int(out[3]))
+        return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), bytes=int(out[3]),
+                    bytes_per_box=int(out[4]), width=int(out[5]), wide_nodes=int(out[6]))
 
     # -- test hooks
     def debug_intersect(self, origins, directions, exclude=None) -> np.ndarray:

@@ -146,8 +146,10 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
  * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "time_kernels". */
 int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);
 
-/* Accel statistics: out[0]=nodes, [1]=leaves, [2]=max depth, [3]=bytes. */
-int crt_accel_stats(crt_ctx *ctx, uint64_t out[4]);
+/* Accel statistics: out[0]=BVH2 inner nodes, [1]=leaves, [2]=max depth, [3]=device bytes,
+ * [4]=bytes of node data fetched per child box tested by crt_trace (32: plain boxes, 16:
+ * 16-bit quantised), [5]=node width crt_trace walks (2 or 4), [6]=inner nodes of that tree. */
+int crt_accel_stats(crt_ctx *ctx, uint64_t out[8]);
 
 /* Test hooks: one closest-hit query per ray through the product's traversal
  * (rays: n x 8 floats ox,oy,oz,dx,dy,dz,exclude_as_u32_bits,_;  out: n x 8:

@@ -895,4 +895,13 @@ int orc_intersect(const orc_scene *sc, const float o[3], const float d[3], uint3
     return 0;
 }
 
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 const char *orc_version(void) { return "crt-oracle 1 (brute force; ComputeShader.wgsl restatement)"; }

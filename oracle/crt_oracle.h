@@ -95,6 +95,9 @@ float orc_hit_pad(const orc_scene *sc);
 /* Camera frame as hoisted to the host: 12 floats llc, horizontal, vertical, eye */
 void orc_camera_frame(const float camera[16], float out[12]);
 
+/* Threads orc_render uses when nthreads <= 0. */
+int orc_max_threads(void);
+
 const char *orc_version(void);
 
 #ifdef __cplusplus

@@ -77,6 +77,7 @@ def lib():
         L.orc_hit_pad.argtypes = [C.POINTER(_Scene)]
         L.orc_camera_frame.restype = None
         L.orc_camera_frame.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
 
@@ -154,6 +155,10 @@ class Scene:
         out = np.zeros(12, np.float32)
         lib().orc_camera_frame(self.camera.ctypes.data, out.ctypes.data)
         return out
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
 
 
 def tea(v0, v1):
