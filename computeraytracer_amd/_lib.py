@@ -45,6 +45,7 @@ SIGNATURES = {
     "crt_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "crt_accel_stats": (C.c_int, [_P, _P]),
     "crt_debug_intersect": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "crt_debug_probes": (C.c_int, [_P, _P]),
     "crt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t]),
 }
 

@@ -131,6 +131,7 @@ struct crt_ctx {
     float last_trace_kernel_ms = 0.0f;
     uint32_t last_trace_kernel_launches = 0;
     uint32_t last_iterations = 0;
+    unsigned long long probes[8] = {0};   // traversal-efficiency probes of the counting kernels
 };
 
 namespace {
@@ -390,8 +391,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     uint32_t P = c->wf_pool ? c->wf_pool : (1u << 21);
     if ((unsigned long long)P > work_total) P = (uint32_t)work_total;
     P = (P + 255u) & ~255u;
-    const uint32_t shade_blocks = P / 256u;
-    const uint32_t list_cap = ((shade_blocks + kWfShards - 1) / kWfShards) * 256u;
+    // list capacity per shard: any shade block size >= 64 maps at most ceil(blocks/shards) blocks to a shard
+    const uint32_t list_cap = ((P / 64u + kWfShards - 1) / kWfShards) * 64u + 256u;
     uint32_t work_per_shard = (uint32_t)((work_total + kWfShards - 1) / kWfShards);
     work_per_shard = (work_per_shard + 63u) & ~63u;
     int rc = wf_ensure(c, P, (size_t)n * npix, (size_t)list_cap * kWfShards);
@@ -457,8 +458,9 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         unsigned long long cur[CRT_NCOUNTERS];
         HIPCHK(c, hipMemcpy(cur, c->d_counters.p, sizeof cur, hipMemcpyDeviceToHost));
         for (int k = 0; k < CRT_NCOUNTERS; k++) cur[k] += c->h_ctl->counters[k];
+        for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl->counters[8 + k];
         HIPCHK(c, hipMemcpy(c->d_counters.p, cur, sizeof cur, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemsetAsync(&c->w_ctl.p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS, c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->w_ctl.p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV, c->stream));
     }
     c->sample += n;
     HIPCHK(c, wf_launch_resolve(W, c->sample, c->stream));
@@ -762,9 +764,17 @@ int crt_enable_counters(crt_ctx *c, int on)
     return CRT_OK;
 }
 
+int crt_debug_probes(crt_ctx *c, uint64_t out[8])
+{
+    if (!c || !out) return CRT_EINVAL;
+    for (int k = 0; k < 8; k++) out[k] = c->probes[k];
+    return CRT_OK;
+}
+
 int crt_reset_counters(crt_ctx *c)
 {
     if (!c) return CRT_EINVAL;
+    for (int k = 0; k < 8; k++) c->probes[k] = 0;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, CRT_NCOUNTERS * sizeof(unsigned long long), c->stream));
     return CRT_OK;

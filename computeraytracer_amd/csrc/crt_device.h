@@ -25,7 +25,7 @@ constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kStackDepth = 32;
 constexpr uint32_t kNLambda = 301;
 constexpr uint32_t kNCie = 471;
-constexpr int CRT_NCOUNTERS_DEV = 8;
+constexpr int CRT_NCOUNTERS_DEV = 16;   // 8 public (crt_counters) + 8 traversal-efficiency probes
 
 struct DevScene {
     const float4 *prim;
@@ -87,6 +87,7 @@ struct WfWork { uint32_t cur, pad[31]; };                    // next work item o
 struct WfCtl {                       // device control block, one per context
     WfShard shard[2][kWfShards];     // indexed by iteration parity
     WfWork work[kWfShards];
+    uint32_t work_done, pad_[31];    // set once every work shard is exhausted (saves the scans)
     unsigned long long counters[CRT_NCOUNTERS_DEV];
 };
 

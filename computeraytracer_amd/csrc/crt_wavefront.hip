@@ -43,6 +43,12 @@ namespace crt {
 #ifndef CRT_WF_BVH4
 #define CRT_WF_BVH4 1
 #endif
+#ifndef CRT_WF_SHADE_BLOCK
+#define CRT_WF_SHADE_BLOCK 256
+#endif
+#ifndef CRT_WF_SHADE_MIN_WAVES
+#define CRT_WF_SHADE_MIN_WAVES 1
+#endif
 #ifndef CRT_WF_MIN_WAVES
 #define CRT_WF_MIN_WAVES 1
 #endif
@@ -87,10 +93,10 @@ __device__ __forceinline__ void wavelengths_of(uint32_t lambda, uint32_t wl[4])
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_shade(const WfParams P, uint32_t it)
+__global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_wf_shade(const WfParams P, uint32_t it)
 {
     const DevScene &S = P.sc;
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t slot = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
     const uint32_t ring = it & 1u;
     WfCtl *ctl = P.ctl;
     if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
@@ -103,47 +109,63 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfParams P, uint32_t it)
 
     PathRegs R;
     R.flags = 0;
-    uint4 misc = uint4{0, 0, 0, 0};
-    if (in_pool) misc = P.misc[slot];
+    // Every per-slot stream is loaded up front in ONE batch (the kernel is bound by dependent
+    // memory round trips, not by bytes: a dead slot's extra 140 B cost nothing next to that).
+    uint4 misc = uint4{0, 0, 0, 0}, rs = uint4{0, 0, 0, 0};
+    float4 v_ro = float4{0, 0, 0, 0}, v_rd = v_ro, v_beta = v_ro, v_rad = v_ro, v_nee = v_ro;
+    float2 h = float2{0.0f, 0.0f};
+    uint32_t vis_in = 0;
+    if (in_pool) {
+        misc = P.misc[slot]; v_ro = P.ray_o[slot]; v_rd = P.ray_d[slot]; v_beta = P.beta[slot];
+        v_rad = P.radiance[slot]; rs = P.rng[slot]; h = P.hit[slot]; vis_in = P.vis[slot]; v_nee = P.nee[slot];
+    }
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
     bool alive = in_pool && (R.flags & kWfAlive);
     bool emit_ext = false, emit_sh = false;
     bool finished = false;
+    // the hit primitive's whole record, also in one batch (valid only for an alive slot with a hit)
+    const uint32_t h_slot = f_bits(h.y);
+    const bool has_hit = alive && !(R.flags & kWfDying) && h_slot != kNoHit;
+    float4 hA = float4{0, 0, 0, 0}, hB = hA, hC = hA, hD = hA;
+    if (has_hit) { hA = S.prim[3 * (size_t)h_slot + 0]; hB = S.prim[3 * (size_t)h_slot + 1]; hC = S.prim[3 * (size_t)h_slot + 2]; hD = S.primD[h_slot]; }
 
     if (alive) {
-        float4 v;
-        v = P.ray_o[slot]; R.ray_o = xyz(v); R.exclude = f_bits(v.w);
-        v = P.ray_d[slot]; R.ray_d = xyz(v);
-        v = P.beta[slot]; R.beta = f4{v.x, v.y, v.z, v.w};
-        v = P.radiance[slot]; R.radiance = f4{v.x, v.y, v.z, v.w};
-        uint4 rs = P.rng[slot]; R.rng = Rng{rs.x, rs.y, rs.z, rs.w};
+        R.ray_o = xyz(v_ro); R.exclude = f_bits(v_ro.w);
+        R.ray_d = xyz(v_rd);
+        R.beta = f4{v_beta.x, v_beta.y, v_beta.z, v_beta.w};
+        R.radiance = f4{v_rad.x, v_rad.y, v_rad.z, v_rad.w};
+        R.rng = Rng{rs.x, rs.y, rs.z, rs.w};
         uint32_t wl[4];
         wavelengths_of((R.flags >> kWfLambdaShift) & 0x1FFu, wl);
         uint32_t depth = (R.flags >> kWfDepthShift) & 0xFFu;
 
         // 1. the NEE term of the previous bounce, now that visibility is known (:187)
         if (R.flags & kWfShadow) {
-            if (P.vis[slot] == 1u) {
-                float4 c = P.nee[slot];
-                R.radiance = R.radiance + f4{c.x, c.y, c.z, c.w};
-            }
+            if (vis_in == 1u) R.radiance = R.radiance + f4{v_nee.x, v_nee.y, v_nee.z, v_nee.w};
             R.flags &= ~kWfShadow;
         }
         if (R.flags & kWfDying) {
             finished = true;                                     // roulette ended it last iteration (:284-287)
         } else {
             // 2. the extension ray's closest hit (:135-146)
-            const float2 h = P.hit[slot];
-            const uint32_t b_slot = f_bits(h.y);
+            const uint32_t b_slot = h_slot;
             if (COUNT) c_bounces++;
             if (b_slot == kNoHit) {
                 finished = true;                                 // :141
             } else {
-                f3 pos, nrm; uint32_t meta;
+                f3 pos, nrm;
                 const f3 o = R.ray_o, d = R.ray_d;
-                hit_attributes(S, b_slot, o, d, h.x, pos, nrm, meta);
+                // hit attributes from the prefetched record (same operations as hit_attributes())
+                const uint32_t meta = f_bits(hA.w);
+                pos = ray_at(o, d, h.x);
+                if ((meta & 3u) == 1u) {
+                    nrm = normalize(pos - xyz(hA));                          // :618
+                } else {
+                    const f3 n0 = ((meta & 3u) == 0u) ? xyz(hD) : normalize(cross(xyz(hB), xyz(hC)));
+                    nrm = (dot(n0, d) > 0.0f) ? -n0 : n0;                    // :541-544
+                }
                 if (COUNT) c_hits++;
-                const uint32_t b_index = f_bits(S.prim[3 * b_slot + 1].w);
+                const uint32_t b_index = f_bits(hB.w);
                 R.exclude = b_index;                             // :146
                 const uint32_t material = (meta >> 2) & 3u;
                 const uint32_t emission_index = (meta >> 4) & 0x3FFFu;
@@ -281,20 +303,33 @@ __global__ __launch_bounds__(256) void k_wf_shade(const WfParams P, uint32_t it)
         const bool want0 = in_pool && !alive;
         bool want = want0;
         const uint32_t lane = lane_id();
-        for (int attempt = 0; attempt < 3; attempt++) {
+        const bool all_done = __hip_atomic_load(&ctl->work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        for (int attempt = 0; attempt < 3 && !all_done; attempt++) {
             const unsigned long long m = __ballot(want);
             if (!m) break;
             const uint32_t sh_lane = lane % kWfShards;
             const unsigned long long lo = (unsigned long long)sh_lane * P.work_per_shard;
             const unsigned long long hi = min(lo + (unsigned long long)P.work_per_shard, P.work_total);
             const uint32_t size_l = hi > lo ? (uint32_t)(hi - lo) : 0u;
-            const uint32_t cur_l = __hip_atomic_load(&ctl->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long avail = __ballot(cur_l < size_l);
-            if (!avail) break;                                   // every shard is exhausted
-            // first non-empty shard at or after this block's own (rotate the mask)
-            const uint32_t rot = my_shard & 63u;
-            const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
-            const uint32_t s_pick = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
+            uint32_t s_pick = my_shard;
+            if (attempt == 0) {
+                // one uniform load of the own cursor: skip the atomic when this shard is already dry
+                const unsigned long long lo0 = (unsigned long long)my_shard * P.work_per_shard;
+                const unsigned long long hi0 = min(lo0 + (unsigned long long)P.work_per_shard, P.work_total);
+                const uint32_t cur0 = __hip_atomic_load(&ctl->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (hi0 <= lo0 || cur0 >= (uint32_t)(hi0 - lo0)) continue;
+            } else {
+                // own shard ran dry: look at every cursor at once (lane i loads shard i) and move on
+                const uint32_t cur_l = __hip_atomic_load(&ctl->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long avail = __ballot(cur_l < size_l);
+                if (!avail) {                                        // every shard is exhausted
+                    if (lane == 0) __hip_atomic_store(&ctl->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                const uint32_t rot = my_shard & 63u;
+                const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
+                s_pick = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
+            }
             const uint32_t n = (uint32_t)__popcll(m);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&ctl->work[s_pick].cur, n);
@@ -464,6 +499,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     int node = 0, sp = 0;
     int nx = 0, ny = 0, nz = 0;                      // 0: lo plane is the near one on that axis, 3: hi plane
     uint32_t c_nodes = 0, c_prims = 0;
+    uint32_t d_inner_it = 0, d_inner_act = 0, d_leaf_it = 0, d_leaf_act = 0, d_prim_it = 0, d_refill = 0, d_refill_lanes = 0;   // lane 0 only
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk
@@ -495,6 +531,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
             }
             if (chunk_pos < chunk_end) {
                 const uint32_t give = min((uint32_t)nidle, chunk_end - chunk_pos);
+                if (COUNT) { d_refill++; d_refill_lanes += give; }
                 const uint32_t my = prefix_popc(idle, lane);
                 if (!active && my < give) {
                     const uint32_t idx = chunk_pos + my;
@@ -547,6 +584,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
             for (int k = 0; k < CRT_WF_INNER_RUN; k++) {
                 const bool inner = active && node >= 0;
                 if (__ballot(inner) == 0ull) break;
+                if (COUNT) { d_inner_it++; d_inner_act += (uint32_t)__popcll(__ballot(inner)); }
                 if (inner) {
 #if CRT_WF_BVH4
                   float k0, k1, k2, k3;
@@ -656,6 +694,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
             // leaf phase: one leaf for every lane that has one
             const bool leaf = active && node < 0;
             if (__ballot(leaf) != 0ull) {
+                if (COUNT) {
+                    d_leaf_it++; d_leaf_act += (uint32_t)__popcll(__ballot(leaf));
+                    uint32_t mc = leaf ? ((~(uint32_t)node) & 7u) + 1u : 0u;
+                    for (int off = 32; off > 0; off >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, off, 64));
+                    d_prim_it += mc;
+                }
                 if (leaf) {
                     const uint32_t enc = ~(uint32_t)node;
                     const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
@@ -684,6 +728,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     if (COUNT) {
         wave_add(ctl->counters + CRT_CNT_NODES, c_nodes);
         wave_add(ctl->counters + CRT_CNT_PRIMS, c_prims);
+        if (lane == 0) {
+            atomicAdd(ctl->counters + 8, (unsigned long long)d_inner_it); atomicAdd(ctl->counters + 9, (unsigned long long)d_inner_act);
+            atomicAdd(ctl->counters + 10, (unsigned long long)d_leaf_it); atomicAdd(ctl->counters + 11, (unsigned long long)d_leaf_act);
+            atomicAdd(ctl->counters + 12, (unsigned long long)d_prim_it); atomicAdd(ctl->counters + 14, (unsigned long long)d_refill);
+            atomicAdd(ctl->counters + 15, (unsigned long long)d_refill_lanes);
+        }
     }
 }
 
@@ -710,6 +760,7 @@ __global__ void k_wf_init(const WfParams P)
     if (i < kWfShards) {
         WfCtl *c = P.ctl;
         c->work[i].cur = 0;
+        if (i == 0) c->work_done = 0;
         c->shard[0][i].n_ext = 0; c->shard[0][i].n_sh = 0; c->shard[0][i].cur = 0;
         c->shard[1][i].n_ext = 0; c->shard[1][i].n_sh = 0; c->shard[1][i].cur = 0;
     }
@@ -724,7 +775,7 @@ hipError_t wf_launch_init(const WfParams &P, hipStream_t s)
 
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
 {
-    const dim3 gs((P.P + 255) / 256), bs(256);
+    const dim3 gs((P.P + CRT_WF_SHADE_BLOCK - 1) / CRT_WF_SHADE_BLOCK), bs(CRT_WF_SHADE_BLOCK);
     if (P.count) hipLaunchKernelGGL((k_wf_shade<true>), gs, bs, 0, s, P, it);
     else hipLaunchKernelGGL((k_wf_shade<false>), gs, bs, 0, s, P, it);
     return hipGetLastError();

@@ -188,6 +188,11 @@ class Renderer:
         self._chk(self._lib.crt_debug_intersect(self._h, rays.ctypes.data, n, out.ctypes.data))
         return out
 
+    def debug_probes(self) -> list:
+        out = np.zeros(8, np.uint64)
+        self._chk(self._lib.crt_debug_probes(self._h, out.ctypes.data))
+        return [int(v) for v in out]
+
     def debug_math(self, fn: int, a, b=None) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), np.float32)

@@ -158,6 +158,9 @@ int crt_accel_stats(crt_ctx *ctx, uint64_t out[8]);
  * 5 pow 6 sqrt 7 div 8 tan). */
 int crt_debug_intersect(crt_ctx *ctx, const float *rays, size_t n, float *out);
 int crt_debug_math(crt_ctx *ctx, int fn, const float *a, const float *b, float *out, size_t n);
+/* Traversal-efficiency probes of the counting kernel variant (wave-level): inner iterations,
+ * lanes active in them, leaf passes, lanes active in them, leaf loop trips, -, refills, lanes refilled. */
+int crt_debug_probes(crt_ctx *ctx, uint64_t out[8]);
 
 #ifdef __cplusplus
 }
