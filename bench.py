@@ -118,11 +118,11 @@ def main():
     r.sync()
     c = r.counters()
     r.enable_counters(False)
-    cnt = torch.tensor([c["rays"], c["nodes"], c["prims"], c["hits"], c["paths"], c["shadow"]], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([c["rays"], c["nodes"], c["prims"], c["hits"], c["paths"], c["shadow"], c["walked"]], dtype=torch.float64, device=dev)
     mine = cnt.clone()
     if world > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    rays, nodes, prims, hits, paths, shadow = [float(v) for v in cnt.tolist()]
+    rays, nodes, prims, hits, paths, shadow, walked = [float(v) for v in cnt.tolist()]
 
     if rank == 0:
         mrays = rays / elapsed / 1e6
@@ -131,7 +131,7 @@ def main():
         # primitive tested, 16 B per closest-hit attribute fetch, 36 B per pixel-sample of
         # framebuffer traffic) over the summed HIP-event durations of its launches in the timed region.
         st = r.accel_stats()
-        m_rays, m_nodes, m_prims, m_hits, m_paths, _ = [float(v) for v in mine.tolist()]
+        m_rays, m_nodes, m_prims, m_hits, m_paths, _, _ = [float(v) for v in mine.tolist()]
         alg_bytes = st["bytes_per_box"] * m_nodes + 48.0 * m_prims + 16.0 * m_hits + 36.0 * m_paths
         per_launch = alg_bytes / max(launches, 1)
         avg_ms = kernel_ms / max(launches, 1)
@@ -149,6 +149,10 @@ def main():
                        "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s)" % t_build},
             "mpaths_per_s": round(paths / elapsed / 1e6, 3),
             "rays_per_path": round(rays / max(paths, 1), 3),
+            "rays": {"intersect_calls": int(rays), "walked_bvh": int(walked), "shadow": int(shadow),
+                     "note": "value counts the reference's intersect() invocations; shadow rays whose NEE term is exactly zero "
+                             "(cos_theta == 0) or whose light primitive is missed are decided without a BVH walk"},
+            "mrays_walked_per_s": round(walked / elapsed / 1e6, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": "k_wf_trace", "launches": launches, "avg_launch_ms": round(avg_ms, 4),

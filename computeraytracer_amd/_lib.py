@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt.so")   # CRT
 
 NCOUNTERS = 8
 ACCEL_NONE, ACCEL_BVH2 = 0, 1
-CNT = dict(rays=0, nodes=1, prims=2, paths=3, bounces=4, shadow=5, hits=6)
+CNT = dict(rays=0, nodes=1, prims=2, paths=3, bounces=4, shadow=5, hits=6, walked=7)
 
 # name -> (restype, argtypes); kept in one place so tests can check that every
 # symbol include/crt.h declares is exported.

@@ -24,8 +24,14 @@ struct Box {
     }
 };
 
-constexpr int kBins = 16;
-constexpr float kCostTrav = 1.2f;   // one inner visit (two boxes, 64 B) vs one primitive test
+#ifndef CRT_BVH_BINS
+#define CRT_BVH_BINS 32
+#endif
+#ifndef CRT_BVH_COST_TRAV
+#define CRT_BVH_COST_TRAV 1.2f
+#endif
+constexpr int kBins = CRT_BVH_BINS;
+constexpr float kCostTrav = CRT_BVH_COST_TRAV;   // one inner visit (two boxes, 64 B) vs one primitive test
 constexpr float kCostIsect = 1.0f;
 
 struct Builder {

@@ -9,7 +9,10 @@ namespace crt {
 
 // Child reference: >= 0 inner node index; < 0 leaf, ~ref = (first << 3) | (count - 1)
 // where first indexes the leaf-ordered primitive array and 1 <= count <= 8.
-constexpr int kMaxLeaf = 4;
+#ifndef CRT_BVH_MAXLEAF
+#define CRT_BVH_MAXLEAF 4
+#endif
+constexpr int kMaxLeaf = CRT_BVH_MAXLEAF;   // <= 8 (leaf encoding)
 constexpr int kMaxDepth = 30;      // deepest leaf; the traversal stack holds 32
 constexpr int kNodeFloats = 16;    // c0.lo c0.hi c1.lo c1.hi ref0 ref1 pad pad  (64 B)
 

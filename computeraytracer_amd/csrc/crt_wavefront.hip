@@ -43,6 +43,9 @@ namespace crt {
 #ifndef CRT_WF_BVH4
 #define CRT_WF_BVH4 1
 #endif
+#ifndef CRT_WF_LEAF_AT
+#define CRT_WF_LEAF_AT 24
+#endif
 #ifndef CRT_WF_SHADE_BLOCK
 #define CRT_WF_SHADE_BLOCK 256
 #endif
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     }
     const uint32_t my_shard = blockIdx.x % kWfShards;
     const bool in_pool = slot < P.P;
-    uint32_t c_rays = 0, c_bounces = 0, c_shadow = 0, c_hits = 0, c_paths = 0, c_prims = 0;
+    uint32_t c_rays = 0, c_bounces = 0, c_shadow = 0, c_hits = 0, c_paths = 0, c_prims = 0, c_walk = 0;
 
     PathRegs R;
     R.flags = 0;
@@ -210,11 +213,14 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                             hit_test<false>(S, S.slot_of_index[include], pos, ldir, b_index, 0.001f, t_l, l_index, l_slot);
                             if (COUNT) c_prims++;
                         }
-                        if (l_slot != kNoHit) {
+                        // cos_theta == 0 (the light sample is behind the surface): le = spec*0 is exactly 0, so the
+                        // NEE term (:400) is exactly +0 whatever the visibility -- adding it changes nothing, and
+                        // the shadow ray need not be walked (weight and pdf are finite: abs_cos >= 1e-5, :366).
+                        const float cos_theta = max_(0.0f, dot(nrm, ldir));
+                        if (l_slot != kNoHit && cos_theta > 0.0f) {
                             f3 lp, ln; uint32_t lmeta;
                             hit_attributes(S, l_slot, pos, ldir, t_l, lp, ln, lmeta);
                             if (COUNT) c_hits++;
-                            float cos_theta = max_(0.0f, dot(nrm, ldir));
                             f4 spec = sample_spectrum(S, f_bits(L0.w), wl);
                             f4 le = spec * cos_theta;
                             float pdf_l = compute_light_pdf(S, (lmeta >> 4) & 0x3FFFu, lp, ln, pos, ldir);
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                             P.vis[slot] = include;
                             emit_sh = true;
                             R.flags |= kWfShadow;
+                            if (COUNT) c_walk++;
                         }
                         // non-finite light direction: the reference loop decides (never seen in practice;
                         // handled by tracing it as a brute-force ray in the mega kernel) -> treated as blocked
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                         depth++;
                         R.flags = (R.flags & ~(0xFFu << kWfDepthShift)) | (depth << kWfDepthShift);
                         emit_ext = true;
-                        if (COUNT) c_rays++;
+                        if (COUNT) { c_rays++; c_walk++; }
                     }
                 }
             }
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                     alive = true;
                     emit_ext = true;
                     emit_sh = false;
-                    if (COUNT) c_rays++;
+                    if (COUNT) { c_rays++; c_walk++; }
                 }
                 // (a work item outside a ragged tile is consumed without a path; the slot retries)
                 else want = true;
@@ -415,6 +422,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         wave_add(ctl->counters + CRT_CNT_HITS, c_hits);
         wave_add(ctl->counters + CRT_CNT_PATHS, c_paths);
         wave_add(ctl->counters + CRT_CNT_PRIMS, c_prims);
+        wave_add(ctl->counters + CRT_CNT_WALKED, c_walk);
     }
 }
 
@@ -490,6 +498,11 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     uint32_t cur_shard = blockIdx.x % kWfShards, sh_n_ext = 0, sh_total = 0;
     uint32_t chunk_pos = 0, chunk_end = 0;
     bool have_shard = false, exhausted = false;
+    {   // start on this block's own shard (its counts are final: written by k_wf_shade); scan only when it is dry
+        const WfShard &so = ctl->shard[ring][cur_shard];
+        sh_n_ext = so.n_ext; sh_total = sh_n_ext + so.n_sh;
+        have_shard = sh_total > 0u;
+    }
     bool active = false;
     // per-lane ray + traversal state
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, id = f3{0, 0, 0}, oid = f3{0, 0, 0};
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     int node = 0, sp = 0;
     int nx = 0, ny = 0, nz = 0;                      // 0: lo plane is the near one on that axis, 3: hi plane
     uint32_t c_nodes = 0, c_prims = 0;
-    uint32_t d_inner_it = 0, d_inner_act = 0, d_leaf_it = 0, d_leaf_act = 0, d_prim_it = 0, d_refill = 0, d_refill_lanes = 0;   // lane 0 only
+    uint32_t d_inner_it = 0, d_inner_act = 0, d_leaf_it = 0, d_leaf_act = 0, d_prim_it = 0, d_refill = 0, d_refill_lanes = 0, d_scans = 0;   // lane 0 only
 
     for (;;) {
         // ---- refill idle lanes from the wave's chunk
@@ -517,6 +530,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     have_shard = false;
                 }
                 // look at every shard at once: lane i loads shard i
+                if (COUNT) d_scans++;
                 const WfShard &sl = ctl->shard[ring][lane % kWfShards];
                 const uint32_t ne = sl.n_ext, tot = ne + sl.n_sh;
                 const uint32_t cur_l = __hip_atomic_load(&sl.cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -576,15 +590,45 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
             continue;
         }
 
-        // ---- traversal bursts
+        // ---- traversal: each pass is either ONE inner-node step for every lane that sits on an inner
+        //      node, or ONE leaf for every lane that holds one.  Leaves are postponed until enough
+        //      lanes hold one (or nothing else can run), so both code blocks run with many lanes on.
 #pragma unroll 1
-        for (int burst = 0; burst < CRT_WF_BURSTS; burst++) {
-            // inner phase: up to kInnerRun box steps; a lane that has found a leaf waits here
-#pragma unroll 1
-            for (int k = 0; k < CRT_WF_INNER_RUN; k++) {
-                const bool inner = active && node >= 0;
-                if (__ballot(inner) == 0ull) break;
-                if (COUNT) { d_inner_it++; d_inner_act += (uint32_t)__popcll(__ballot(inner)); }
+        for (int pass = 0; pass < 64; pass++) {
+            const bool inner = active && node >= 0;
+            const bool leaf = active && node < 0;
+            const int ni = __popcll(__ballot(inner)), nl = __popcll(__ballot(leaf));
+            if (ni + nl == 0) break;
+            if (!exhausted && 64 - (ni + nl) >= kRefillAt && pass > 0) break;     // enough idle lanes: refill first
+            if (nl >= CRT_WF_LEAF_AT || ni == 0) {
+                if (COUNT) {
+                    d_leaf_it++; d_leaf_act += (uint32_t)nl;
+                    uint32_t mc = leaf ? ((~(uint32_t)node) & 7u) + 1u : 0u;
+                    for (int off = 32; off > 0; off >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, off, 64));
+                    d_prim_it += mc;
+                }
+                if (leaf) {
+                    const uint32_t enc = ~(uint32_t)node;
+                    const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+                    for (uint32_t i = 0; i < cnt; i++) {
+                        const uint32_t ps = first + i;
+                        const float4 A = prim[3 * (size_t)ps + 0], B = prim[3 * (size_t)ps + 1], C = prim[3 * (size_t)ps + 2];
+                        if ((f_bits(A.w) & 3u) == 2u) tri_test(A, B, C, ps, o, d, excl, t_min, hit_pad, t_max, b_index, b_slot);
+                        else hit_test<false>(S, ps, o, d, excl, t_min, t_max, b_index, b_slot);
+                    }
+                    if (COUNT) c_prims += cnt;
+                    bool done = false;
+                    if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
+                    else if (sp > 0) { sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl]; }
+                    else done = true;
+                    if (done) {
+                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                        active = false;
+                    }
+                }
+            } else {
+                if (COUNT) { d_inner_it++; d_inner_act += (uint32_t)ni; }
                 if (inner) {
 #if CRT_WF_BVH4
                   float k0, k1, k2, k3;
@@ -691,38 +735,6 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
 #endif
                 }
             }
-            // leaf phase: one leaf for every lane that has one
-            const bool leaf = active && node < 0;
-            if (__ballot(leaf) != 0ull) {
-                if (COUNT) {
-                    d_leaf_it++; d_leaf_act += (uint32_t)__popcll(__ballot(leaf));
-                    uint32_t mc = leaf ? ((~(uint32_t)node) & 7u) + 1u : 0u;
-                    for (int off = 32; off > 0; off >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, off, 64));
-                    d_prim_it += mc;
-                }
-                if (leaf) {
-                    const uint32_t enc = ~(uint32_t)node;
-                    const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-                    for (uint32_t i = 0; i < cnt; i++) {
-                        const uint32_t ps = first + i;
-                        const float4 A = prim[3 * (size_t)ps + 0], B = prim[3 * (size_t)ps + 1], C = prim[3 * (size_t)ps + 2];
-                        if ((f_bits(A.w) & 3u) == 2u) tri_test(A, B, C, ps, o, d, excl, t_min, hit_pad, t_max, b_index, b_slot);
-                        else hit_test<false>(S, ps, o, d, excl, t_min, t_max, b_index, b_slot);
-                    }
-                    if (COUNT) c_prims += cnt;
-                    bool done = false;
-                    if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
-                    else if (sp > 0) { sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl]; }
-                    else done = true;
-                    if (done) {
-                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
-                        active = false;
-                    }
-                }
-            }
-            const int nact = __popcll(__ballot(active));
-            if (nact == 0 || (nact <= 64 - kRefillAt && !exhausted)) break;
         }
     }
     if (COUNT) {
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
         if (lane == 0) {
             atomicAdd(ctl->counters + 8, (unsigned long long)d_inner_it); atomicAdd(ctl->counters + 9, (unsigned long long)d_inner_act);
             atomicAdd(ctl->counters + 10, (unsigned long long)d_leaf_it); atomicAdd(ctl->counters + 11, (unsigned long long)d_leaf_act);
-            atomicAdd(ctl->counters + 12, (unsigned long long)d_prim_it); atomicAdd(ctl->counters + 14, (unsigned long long)d_refill);
+            atomicAdd(ctl->counters + 12, (unsigned long long)d_prim_it); atomicAdd(ctl->counters + 13, (unsigned long long)d_scans); atomicAdd(ctl->counters + 14, (unsigned long long)d_refill);
             atomicAdd(ctl->counters + 15, (unsigned long long)d_refill_lanes);
         }
     }

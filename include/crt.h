@@ -56,7 +56,9 @@ enum {
     CRT_CNT_BOUNCES = 4,     /* path-loop iterations                            */
     CRT_CNT_SHADOW = 5,      /* shadow rays (subset of RAYS)                    */
     CRT_CNT_HITS = 6,        /* closest-hit attribute fetches                   */
-    CRT_CNT_RESERVED = 7,
+    CRT_CNT_WALKED = 7,      /* rays that actually walked the BVH: RAYS minus shadow rays decided
+                                without a walk (light's own primitive missed, or cos_theta == 0 so the
+                                NEE term is exactly zero) -- wavefront pipeline only                  */
     CRT_NCOUNTERS = 8
 };
 
