@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64, help="samples per step (BASELINE config 3: 64)")
     ap.add_argument("--soup-tris", type=int, default=10_000_000)
+    ap.add_argument("--band", type=int, default=8, help="rows per interleaved band for N>1 (0 = contiguous strips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", default="256x144", help="oracle sample: centre crop WxH at 1 spp")
     args = ap.parse_args()
@@ -69,9 +70,8 @@ def main():
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     r.set_option("time_kernels", 1)     # HIP events around every launch of the traversal kernel
     r.upload(ps)
-    sf = StripFrame(W, H, world, rank, dev)
-    y0, y1 = sf.y0, sf.y1
-    r.set_tile(*sf.tile)
+    sf = StripFrame(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
+    sf.apply(r)
     t0 = time.time()
     r.build_accel("bvh2")
     t_build = time.time() - t0
@@ -80,7 +80,8 @@ def main():
 
     def step():
         r.frame(args.spp)
-        sf.gather()         # the path's one exchange step: all_gather of the strips (RCCL over xGMI)
+        sf.gather(accum=False)   # the path's one exchange step: all_gather of the rgba8 strips (RCCL over xGMI);
+                                 # the accumulator stays on its GPU like the reference's (gathered once at the end)
 
     def barrier():
         torch.cuda.synchronize()
@@ -102,6 +103,7 @@ def main():
         total_ms += r.last_trace_ms()[0]
     barrier()
     elapsed = time.perf_counter() - t0
+    sf.gather(accum=True)      # final readout of the f32 XYZ accumulator (outside the timed steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -111,7 +113,7 @@ def main():
     # (scene, pixel, sample), so re-running the same sample range with the counting kernel
     # variant (untimed) gives the exact counts.
     r.reset()
-    r.write_accum(np.zeros((y1 - y0, W, 4), np.float32), args.warmup * args.spp)
+    r.write_accum(np.zeros((sf.local_rows, W, 4), np.float32), args.warmup * args.spp)
     r.enable_counters(True).reset_counters()
     for _ in range(args.steps):
         r.frame(args.spp)
@@ -145,7 +147,8 @@ def main():
             "config": {"workload": f"S2 {args.scene}: {ntri} triangles + cornell walls/light, {W}x{H}, "
                                    f"{args.spp} spp per step (BASELINE config 3)" if args.scene == "atrium250k" else
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
-                       "partition": f"{world} horizontal strip(s), scene replicated, all_gather of strips per step",
+                       "partition": (f"rows dealt to {world} GPUs in bands of {args.band}" if world > 1 and args.band else f"{world} horizontal strip(s)")
+                                    + ", scene replicated, all_gather of the rgba8 strips per step",
                        "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s)" % t_build},
             "mpaths_per_s": round(paths / elapsed / 1e6, 3),
             "rays_per_path": round(rays / max(paths, 1), 3),

@@ -25,6 +25,7 @@ SIGNATURES = {
     "crt_abi_version": (C.c_int, []),
     "crt_upload_scene": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P, _P]),
     "crt_set_tile": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "crt_set_row_bands": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "crt_build_accel": (C.c_int, [_P, C.c_int]),
     "crt_reset": (C.c_int, [_P]),
     "crt_trace": (C.c_int, [_P, C.c_uint32]),

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -101,6 +102,7 @@ struct crt_ctx {
 
     // tile + outputs
     uint32_t x0 = 0, y0 = 0, tw = 0, th = 0;
+    uint32_t band = 0x40000000u, stride = 1, phase = 0;   // row interleave (rectangular tile by default)
     DevBuf<float4> d_accum;
     DevBuf<uchar4> d_rgba;
     float4 *accum_bound = nullptr;
@@ -124,8 +126,8 @@ struct crt_ctx {
     DevBuf<float2> w_hit;
     DevBuf<uint32_t> w_vis, w_list_ext, w_list_sh;
     DevBuf<WfCtl> w_ctl;
-    WfCtl *h_ctl = nullptr;         // pinned
-    hipEvent_t ev_ctl = nullptr;
+    WfCtl *h_ctl[2] = {nullptr, nullptr};   // pinned, double-buffered status readbacks
+    hipEvent_t ev_ctl[2] = {nullptr, nullptr};
     bool time_kernels = false;
     std::vector<hipEvent_t> kev;    // event pairs around k_wf_trace launches
     float last_trace_kernel_ms = 0.0f;
@@ -353,7 +355,7 @@ int upload_geometry(crt_ctx *c, int mode)
 // ---------------------------------------------------------------- wavefront driver
 int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
 {
-    if (c->w_list_ext.n < list_elems) { HIPCHK(c, c->w_list_ext.alloc(list_elems)); HIPCHK(c, c->w_list_sh.alloc(list_elems)); }
+    if (c->w_list_ext.n < 2 * list_elems) { HIPCHK(c, c->w_list_ext.alloc(2 * list_elems)); HIPCHK(c, c->w_list_sh.alloc(2 * list_elems)); }
     if (c->w_misc.n < P) {
         HIPCHK(c, c->w_ray_o.alloc(P)); HIPCHK(c, c->w_ray_d.alloc(P)); HIPCHK(c, c->w_sh_d.alloc(P));
         HIPCHK(c, c->w_beta.alloc(P)); HIPCHK(c, c->w_radiance.alloc(P)); HIPCHK(c, c->w_nee.alloc(P));
@@ -364,8 +366,10 @@ int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
     if (!c->w_ctl.p) {
         HIPCHK(c, c->w_ctl.alloc(1));
         HIPCHK(c, hipMemset(c->w_ctl.p, 0, sizeof(WfCtl)));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(WfCtl), hipHostMallocDefault));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl, hipEventDisableTiming));
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(c, hipHostMalloc((void **)&c->h_ctl[b], sizeof(WfCtl), hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl[b], hipEventDisableTiming));
+        }
     }
     if (c->num_cu == 0) {
         hipDeviceProp_t prop;
@@ -402,9 +406,12 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     W.sc = c->sc;
     W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
     W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
-    W.hit = c->w_hit.p; W.vis = c->w_vis.p; W.list_ext = c->w_list_ext.p; W.list_sh = c->w_list_sh.p;
+    W.hit = c->w_hit.p; W.vis = c->w_vis.p;
+    W.list_ext[0] = c->w_list_ext.p; W.list_ext[1] = c->w_list_ext.p + (size_t)list_cap * kWfShards;
+    W.list_sh[0] = c->w_list_sh.p; W.list_sh[1] = c->w_list_sh.p + (size_t)list_cap * kWfShards;
     W.staging = c->w_staging.p; W.ctl = c->w_ctl.p;
     W.P = P; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
+    W.band = c->band; W.stride = c->stride; W.phase = c->phase;
     W.tiles_x = tiles_x; W.tiles_y = tiles_y; W.npix_padded = npix_padded; W.work_total = work_total;
     W.work_per_shard = work_per_shard; W.list_cap = list_cap;
     W.first_sample = c->sample + 1; W.n_samples = n;
@@ -415,9 +422,14 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     const uint32_t trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
 
     HIPCHK(c, wf_launch_init(W, c->stream));
-    uint32_t it = 0;
-    uint32_t chunk = 8;
-    for (;;) {
+    // Iterations are enqueued in chunks; after each chunk the small control block is copied back
+    // (asynchronously) so the host can tell when the pool has drained.  One chunk is always
+    // enqueued AHEAD of the status being waited for, so the GPU never idles on the host; the
+    // price is at most one chunk of empty iterations at the end.
+    uint32_t it = 0, chunk = 4, tail_bound = 0, blocks_now = trace_blocks;
+    uint32_t it_end[2] = {0, 0};
+    auto enqueue_chunk = [&](int buf) -> int {
+        W.tail_bound = tail_bound;
         for (uint32_t k = 0; k < chunk; k++, it++) {
             HIPCHK(c, wf_launch_shade(W, it, c->stream));
             if (c->time_kernels) {
@@ -429,36 +441,57 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
                 }
                 HIPCHK(c, hipEventRecord(c->kev[need - 2], c->stream));
             }
-            HIPCHK(c, wf_launch_trace(W, it, trace_blocks, c->stream));
+            HIPCHK(c, wf_launch_trace(W, it, blocks_now, c->stream));
             if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], c->stream));
             c->last_trace_kernel_launches++;
             c->last_launches += 2;
         }
-        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev_ctl, c->stream));
-        HIPCHK(c, hipEventSynchronize(c->ev_ctl));
+        it_end[buf] = it;
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl[buf], c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_ctl[buf], c->stream));
+        return CRT_OK;
+    };
+    int cur = 0;
+    rc = enqueue_chunk(cur);
+    if (rc) return rc;
+    for (;;) {
+        rc = enqueue_chunk(cur ^ 1);                           // speculative: keeps the GPU busy during the wait
+        if (rc) return rc;
+        HIPCHK(c, hipEventSynchronize(c->ev_ctl[cur]));
+        const WfCtl *hc = c->h_ctl[cur];
         bool work_left = false;
         unsigned long long rays = 0;
+        uint32_t bound = 0;
         for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
             const unsigned long long lo = (unsigned long long)sidx * work_per_shard;
             const unsigned long long size = lo < work_total ? std::min<unsigned long long>(work_per_shard, work_total - lo) : 0;
-            if (c->h_ctl->work[sidx].cur < size) work_left = true;
-            const WfShard &sh = c->h_ctl->shard[(it - 1) & 1u][sidx];
+            if (hc->work[sidx].cur < size) work_left = true;
+            const WfShard &sh = hc->shard[(it_end[cur] - 1) & 3u][sidx];
             rays += (unsigned long long)sh.n_ext + sh.n_sh;
+            bound = std::max(bound, std::max(sh.n_ext, sh.n_sh));
         }
+        if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] it %u rays %llu work_left %d bound %u\n", it_end[cur], rays, (int)work_left, bound);
         if (!work_left && rays == 0) break;                     // every slot alive after a shade pass lists a ray
-        if (!work_left) chunk = 2;                               // tail: only long paths are left
+        if (!work_left) {
+            // The tail: no path can start any more, so ray counts only shrink from here.  Once few
+            // are left, shade walks the ray lists instead of the whole pool and the grids shrink.
+            if (rays < (unsigned long long)P / 4u) {
+                tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
+                blocks_now = (uint32_t)std::min<unsigned long long>(trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
+            }
+        }
         if (it > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+        cur ^= 1;
     }
     c->last_iterations += it;
     if (c->counting) {
         // fold the pipeline's counters into the context's
-        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl[0], c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         unsigned long long cur[CRT_NCOUNTERS];
         HIPCHK(c, hipMemcpy(cur, c->d_counters.p, sizeof cur, hipMemcpyDeviceToHost));
-        for (int k = 0; k < CRT_NCOUNTERS; k++) cur[k] += c->h_ctl->counters[k];
-        for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl->counters[8 + k];
+        for (int k = 0; k < CRT_NCOUNTERS; k++) cur[k] += c->h_ctl[0]->counters[k];
+        for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl[0]->counters[8 + k];
         HIPCHK(c, hipMemcpy(c->d_counters.p, cur, sizeof cur, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemsetAsync(&c->w_ctl.p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV, c->stream));
     }
@@ -514,8 +547,10 @@ void crt_destroy(crt_ctx *c)
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); c->w_staging.release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
     c->w_vis.release(); c->w_list_ext.release(); c->w_list_sh.release(); c->w_ctl.release();
-    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    if (c->ev_ctl) (void)hipEventDestroy(c->ev_ctl);
+    for (int b = 0; b < 2; b++) {
+        if (c->h_ctl[b]) (void)hipHostFree(c->h_ctl[b]);
+        if (c->ev_ctl[b]) (void)hipEventDestroy(c->ev_ctl[b]);
+    }
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -587,6 +622,7 @@ int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const voi
     c->have_scene = true;
     c->accel_mode = -1;
     c->x0 = 0; c->y0 = 0; c->tw = c->W; c->th = c->H;
+    c->band = 0x40000000u; c->stride = 1; c->phase = 0;
     c->accum_bound = nullptr; c->rgba_bound = nullptr;
     int rc = alloc_tile(c);
     if (rc) return rc;
@@ -602,6 +638,26 @@ int crt_set_tile(crt_ctx *c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->x0 = x0; c->y0 = y0; c->tw = x1 - x0; c->th = y1 - y0;
+    c->band = 0x40000000u; c->stride = 1; c->phase = 0;
+    c->accum_bound = nullptr; c->rgba_bound = nullptr;
+    int rc = alloc_tile(c);
+    if (rc) return rc;
+    return zero_state(c);
+}
+
+int crt_set_row_bands(crt_ctx *c, uint32_t band_rows, uint32_t parts, uint32_t part)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_set_row_bands: upload a scene first");
+    if (band_rows == 0 || parts == 0 || part >= parts || band_rows > 65536u)
+        return fail(c, CRT_EINVAL, "crt_set_row_bands: need band_rows >= 1 and part < parts");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t rows = 0;                                   // rows y of the frame with (y / band) % parts == part
+    for (uint32_t b = part; (unsigned long long)b * band_rows < c->H; b += parts)
+        rows += std::min<uint32_t>(band_rows, c->H - b * band_rows);
+    c->x0 = 0; c->y0 = 0; c->tw = c->W; c->th = rows;
+    c->band = band_rows; c->stride = parts; c->phase = part;
     c->accum_bound = nullptr; c->rgba_bound = nullptr;
     int rc = alloc_tile(c);
     if (rc) return rc;
@@ -635,6 +691,7 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
     TraceParams P{};
     P.sc = c->sc;
     P.x0 = c->x0; P.y0 = c->y0; P.tw = c->tw; P.th = c->th;
+    P.band = c->band; P.stride = c->stride; P.phase = c->phase;
     P.accum = accum_ptr(c); P.rgba = rgba_ptr(c);
     P.counters = c->counting ? c->d_counters.p : nullptr;
     P.tiles_x = (c->tw + 7) / 8; P.tiles_y = (c->th + 7) / 8;        // main.js:606-610

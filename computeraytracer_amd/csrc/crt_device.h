@@ -51,7 +51,8 @@ struct DevScene {
 
 struct TraceParams {
     DevScene sc;
-    uint32_t x0, y0, tw, th;        // tile rectangle
+    uint32_t x0, y0, tw, th;        // tile rectangle (local buffer is tw x th)
+    uint32_t band, stride, phase;   // row interleave: global y = y0 + (ly/band)*band*stride + phase*band + ly%band
     uint32_t first_sample, n_samples;
     float4 *accum;
     uchar4 *rgba;
@@ -85,7 +86,7 @@ constexpr uint32_t kWfShards = 64;
 struct WfShard { uint32_t n_ext, n_sh, cur, pad[29]; };     // rays listed by shade / fetch cursor of trace
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
-    WfShard shard[2][kWfShards];     // indexed by iteration parity
+    WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
     WfWork work[kWfShards];
     uint32_t work_done, pad_[31];    // set once every work shard is exhausted (saves the scans)
     unsigned long long counters[CRT_NCOUNTERS_DEV];
@@ -97,16 +98,19 @@ struct WfParams {
     uint4 *rng, *misc;
     float2 *hit;
     uint32_t *vis;
-    uint32_t *list_ext, *list_sh;
+    uint32_t *list_ext[2], *list_sh[2];   // double-buffered by iteration parity
     float4 *staging;
     WfCtl *ctl;
     uint32_t P;                      // pool size (slots)
-    uint32_t x0, y0, tw, th;         // tile rectangle
+    uint32_t x0, y0, tw, th;         // tile rectangle (local buffer is tw x th)
+    uint32_t band, stride, phase;    // row interleave: global y = y0 + (ly/band)*band*stride + phase*band + ly%band
     uint32_t tiles_x, tiles_y;
     uint32_t npix_padded;            // tiles_x*tiles_y*64: work item = sample_off * npix_padded + tile*64 + lane
     unsigned long long work_total;   // n_samples * npix_padded
     uint32_t work_per_shard;         // work items per shard (multiple of 64)
     uint32_t list_cap;               // list entries per shard
+    uint32_t tail_bound;             // 0: one shade thread per slot; >0: tail mode, threads walk the previous
+                                     //    iteration's ray lists (<= tail_bound entries per shard and list)
     uint32_t first_sample, n_samples;
     float4 *accum;
     uchar4 *rgba;

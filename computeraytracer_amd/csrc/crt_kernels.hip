@@ -40,7 +40,8 @@ __global__ __launch_bounds__(64) void k_trace(const TraceParams P)
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const uint32_t lx = tx * 8u + (lane & 7u), ly = ty * 8u + (lane >> 3);
     const bool in_tile = lx < P.tw && ly < P.th;
-    const uint32_t px = P.x0 + lx, py = P.y0 + ly;             // GLOBAL pixel (seeds, film position)
+    const uint32_t px = P.x0 + lx;                             // GLOBAL pixel (seeds, film position)
+    const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
     const size_t pix = (size_t)lx + (size_t)ly * P.tw;
 
     uint32_t c_rays = 0, c_nodes = 0, c_prims = 0, c_bounces = 0, c_shadow = 0, c_hits = 0;

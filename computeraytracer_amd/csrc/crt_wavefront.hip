@@ -99,15 +99,35 @@ template <bool COUNT>
 __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_wf_shade(const WfParams P, uint32_t it)
 {
     const DevScene &S = P.sc;
-    const uint32_t slot = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
-    const uint32_t ring = it & 1u;
+    const uint32_t ring = it & 3u, lbuf = it & 1u;
     WfCtl *ctl = P.ctl;
     if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
-        WfShard &nx = ctl->shard[ring ^ 1u][threadIdx.x];        // (its last reader, trace(it-1), is done)
+        WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
         nx.n_ext = 0; nx.n_sh = 0; nx.cur = 0;
     }
-    const uint32_t my_shard = blockIdx.x % kWfShards;
-    const bool in_pool = slot < P.P;
+    uint32_t slot, my_shard;
+    bool in_pool, via_shadow_list = false;
+    if (P.tail_bound == 0u) {
+        slot = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
+        my_shard = blockIdx.x % kWfShards;
+        in_pool = slot < P.P;
+    } else {
+        // Tail mode (no work left, few paths alive): every alive slot listed a ray last iteration,
+        // so walk those lists instead of the whole pool.  Per shard: threads [0,bound) take the
+        // extension list, [bound,2*bound) the shadow list (only slots that are dying, i.e. not
+        // also in the extension list).
+        const uint32_t bps = (2u * P.tail_bound + (uint32_t)CRT_WF_SHADE_BLOCK - 1u) / (uint32_t)CRT_WF_SHADE_BLOCK;
+        my_shard = blockIdx.x / bps;
+        const uint32_t j = (blockIdx.x % bps) * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
+        const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
+        const size_t region = (size_t)my_shard * P.list_cap;
+        slot = 0; in_pool = false;
+        if (j < P.tail_bound) {
+            if (j < pv.n_ext) { slot = P.list_ext[lbuf ^ 1u][region + j]; in_pool = true; }
+        } else if (j - P.tail_bound < pv.n_sh && j < 2u * P.tail_bound) {
+            slot = P.list_sh[lbuf ^ 1u][region + (j - P.tail_bound)]; in_pool = true; via_shadow_list = true;
+        }
+    }
     uint32_t c_rays = 0, c_bounces = 0, c_shadow = 0, c_hits = 0, c_paths = 0, c_prims = 0, c_walk = 0;
 
     PathRegs R;
@@ -123,6 +143,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         v_rad = P.radiance[slot]; rs = P.rng[slot]; h = P.hit[slot]; vis_in = P.vis[slot]; v_nee = P.nee[slot];
     }
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
+    if (via_shadow_list && !(R.flags & kWfDying)) in_pool = false;   // reached through its extension ray instead
     bool alive = in_pool && (R.flags & kWfAlive);
     bool emit_ext = false, emit_sh = false;
     bool finished = false;
@@ -352,7 +373,8 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                 const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
                 R.flags = 0;
                 if (lx < P.tw && ly < P.th) {
-                    const uint32_t px = P.x0 + lx, py = P.y0 + ly, sample = P.first_sample + sample_off;
+                    const uint32_t px = P.x0 + lx, sample = P.first_sample + sample_off;
+                    const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
                     R.rng = Rng{py, px * 100u, sample, tea(px, py * 100u)};                  // :98
                     float jx = rnd(R.rng);
                     float fs = ((float)px + ((float)(sample % kGrid) + jx) / (float)kGrid) / (float)S.W;
@@ -412,8 +434,8 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         }
         be = __shfl(be, 0, 64); bs = __shfl(bs, 0, 64);
         const size_t region = (size_t)my_shard * P.list_cap;
-        if (emit_ext) P.list_ext[region + be + prefix_popc(me, lane)] = slot;
-        if (emit_sh) P.list_sh[region + bs + prefix_popc(ms, lane)] = slot;
+        if (emit_ext) P.list_ext[lbuf][region + be + prefix_popc(me, lane)] = slot;
+        if (emit_sh) P.list_sh[lbuf][region + bs + prefix_popc(ms, lane)] = slot;
     }
     if (COUNT) {
         wave_add(ctl->counters + CRT_CNT_RAYS, c_rays);
@@ -479,8 +501,8 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     const float4 *__restrict__ g_sh_d = P.sh_d;
     uint32_t *__restrict__ g_vis = P.vis;
     float2 *__restrict__ g_hit = P.hit;
-    const uint32_t *__restrict__ list_ext = P.list_ext;
-    const uint32_t *__restrict__ list_sh = P.list_sh;
+    const uint32_t *__restrict__ list_ext = P.list_ext[it & 1u];
+    const uint32_t *__restrict__ list_sh = P.list_sh[it & 1u];
     const float hit_pad = P.sc.hit_pad;
     const int root = CRT_WF_BVH4 ? P.sc.root4 : P.sc.root;
     int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
@@ -489,7 +511,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     DevScene S = P.sc;                                         // for the rare patch / sphere tests
     S.prim = prim; S.primD = primD;
 
-    const uint32_t ring = it & 1u;
+    const uint32_t ring = it & 3u;
     const uint32_t lane = lane_id();
     int *stk = lds_stack + lane;
     const float t_min = 0.001f;
@@ -773,8 +795,7 @@ __global__ void k_wf_init(const WfParams P)
         WfCtl *c = P.ctl;
         c->work[i].cur = 0;
         if (i == 0) c->work_done = 0;
-        c->shard[0][i].n_ext = 0; c->shard[0][i].n_sh = 0; c->shard[0][i].cur = 0;
-        c->shard[1][i].n_ext = 0; c->shard[1][i].n_sh = 0; c->shard[1][i].cur = 0;
+        for (int r = 0; r < 4; r++) { c->shard[r][i].n_ext = 0; c->shard[r][i].n_sh = 0; c->shard[r][i].cur = 0; }
     }
 }
 
@@ -787,7 +808,8 @@ hipError_t wf_launch_init(const WfParams &P, hipStream_t s)
 
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
 {
-    const dim3 gs((P.P + CRT_WF_SHADE_BLOCK - 1) / CRT_WF_SHADE_BLOCK), bs(CRT_WF_SHADE_BLOCK);
+    const uint32_t bps = (2u * P.tail_bound + CRT_WF_SHADE_BLOCK - 1u) / CRT_WF_SHADE_BLOCK;
+    const dim3 gs(P.tail_bound ? kWfShards * bps : (P.P + CRT_WF_SHADE_BLOCK - 1) / CRT_WF_SHADE_BLOCK), bs(CRT_WF_SHADE_BLOCK);
     if (P.count) hipLaunchKernelGGL((k_wf_shade<true>), gs, bs, 0, s, P, it);
     else hipLaunchKernelGGL((k_wf_shade<false>), gs, bs, 0, s, P, it);
     return hipGetLastError();

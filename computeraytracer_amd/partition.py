@@ -32,3 +32,13 @@ def assemble(strips, height: int):
     except ImportError:
         pass
     return np.concatenate(parts, 0)
+
+
+def band_rows(height: int, world: int, rank: int, band: int = 8):
+    """Global row indices of rank `rank` under the row-interleaved partition (bands of `band`
+    rows dealt round-robin): rows y with (y // band) % world == rank, in local order."""
+    import numpy as np
+    if world < 1 or not (0 <= rank < world) or band < 1:
+        raise ValueError("bad world/rank/band")
+    y = np.arange(height)
+    return y[(y // band) % world == rank]

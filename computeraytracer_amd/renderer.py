@@ -76,6 +76,10 @@ class Renderer:
         self._chk(self._lib.crt_set_tile(self._h, x0, y0, x1, y1))
         return self
 
+    def set_row_bands(self, band_rows: int, parts: int, part: int):
+        self._chk(self._lib.crt_set_row_bands(self._h, band_rows, parts, part))
+        return self
+
     def build_accel(self, mode="bvh2"):
         self._chk(self._lib.crt_build_accel(self._h, _ACCEL[mode]))
         return self

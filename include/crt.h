@@ -92,6 +92,12 @@ int crt_upload_scene(crt_ctx *ctx,
  * accumulator. */
 int crt_set_tile(crt_ctx *ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 
+/* Row-interleaved partition for load balance across GPUs: this context renders the rows y of
+ * the full frame with (y / band_rows) % parts == part, full width, packed densely in its
+ * buffers (local row j is global row ((j / band) * parts + part) * band + j % band).
+ * Resets the accumulator.  crt_set_tile returns to a plain rectangle. */
+int crt_set_row_bands(crt_ctx *ctx, uint32_t band_rows, uint32_t parts, uint32_t part);
+
 int crt_build_accel(crt_ctx *ctx, int mode);
 
 /* ~ main.js:298-311: zero alt_color_buffer, sample = 0. */

@@ -33,7 +33,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, spp, out_dir):
+def _worker(rank, world, port, W, H, spp, out_dir, band=0):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -44,11 +44,22 @@ def _worker(rank, world, port, W, H, spp, out_dir):
     from oracle import orc
     ps = cornell(W, H)
     sc = orc.Scene.from_packed(ps)
-    sf = StripFrame(W, H, world, rank, "cpu")
-    x0, y0, x1, y1 = sf.tile
-    acc, rgba, _ = sc.render(spp, rect=(x0, y0, x1, y1), nthreads=2)
-    sf.accum[: y1 - y0] = torch.from_numpy(acc[y0:y1])
-    sf.rgba[: y1 - y0] = torch.from_numpy(rgba[y0:y1])
+    sf = StripFrame(W, H, world, rank, "cpu", band=band)
+    if band:
+        rows = sf.rows[rank]
+        acc = np.zeros((H, W, 4), np.float32)
+        rgba = np.zeros((H, W, 4), np.uint8)
+        for y in range(0, H, band):
+            if (y // band) % world == rank:
+                a, r, _ = sc.render(spp, rect=(0, y, W, min(y + band, H)), nthreads=2)
+                acc[y:y + band], rgba[y:y + band] = a[y:y + band], r[y:y + band]
+        sf.accum[: len(rows)] = torch.from_numpy(acc[rows])
+        sf.rgba[: len(rows)] = torch.from_numpy(rgba[rows])
+    else:
+        x0, y0, x1, y1 = sf.tile
+        acc, rgba, _ = sc.render(spp, rect=(x0, y0, x1, y1), nthreads=2)
+        sf.accum[: y1 - y0] = torch.from_numpy(acc[y0:y1])
+        sf.rgba[: y1 - y0] = torch.from_numpy(rgba[y0:y1])
     sf.gather()
     a, r = sf.image()
     np.save(os.path.join(out_dir, f"acc{rank}.npy"), a.numpy())
@@ -57,10 +68,19 @@ def _worker(rank, world, port, W, H, spp, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("H", [64, 61])          # even split and a short last strip
-def test_two_rank_gather_equals_single_process(tmp_path, orc, H):
+def test_band_rows_partition_covers_the_frame():
+    from computeraytracer_amd.partition import band_rows
+    for H, world, band in [(1080, 8, 8), (363, 3, 5), (7, 4, 8), (64, 2, 8)]:
+        parts = [band_rows(H, world, r, band) for r in range(world)]
+        allrows = np.sort(np.concatenate(parts))
+        assert np.array_equal(allrows, np.arange(H))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= band
+
+
+@pytest.mark.parametrize("H,band", [(64, 0), (61, 0), (61, 8)])   # even split, short last strip, interleaved bands
+def test_two_rank_gather_equals_single_process(tmp_path, orc, H, band):
     W, spp, world = 80, 2, 2
-    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, H, spp, str(tmp_path), band), nprocs=world, join=True)
     from computeraytracer_amd import cornell
     acc_o, rgba_o, _ = orc.Scene.from_packed(cornell(W, H)).render(spp)
     for rank in range(world):                     # all_gather: every rank holds the frame

@@ -222,6 +222,26 @@ def test_tile_partition_is_bit_identical_1080p(renderer):
         assert np.array_equal(renderer.read_rgba8(), full_rgba[y0:y1, x0:x1])
 
 
+def test_row_band_partition_is_bit_identical(renderer):
+    """Row-interleaved partition (bands dealt round-robin): each part equals those rows of the frame."""
+    from computeraytracer_amd.partition import band_rows
+    from computeraytracer_amd.scenes_synth import mesh10k
+    ps = mesh10k(640, 363)                       # height not a multiple of band * parts
+    full_acc, full_rgba = render(renderer, ps, 3)
+    for parts, band in [(4, 8), (3, 5), (8, 8)]:
+        seen = np.zeros(363, bool)
+        for part in range(parts):
+            rows = band_rows(363, parts, part, band)
+            renderer.set_row_bands(band, parts, part)
+            renderer.frame(3).sync()
+            acc, rgba = renderer.read_accum(), renderer.read_rgba8()
+            assert acc.shape == (len(rows), 640, 4)
+            assert np.array_equal(bits(acc), bits(full_acc[rows])) and np.array_equal(rgba, full_rgba[rows])
+            seen[rows] = True
+        assert seen.all()
+    renderer.set_tile(0, 0, 640, 363)
+
+
 def test_fused_samples_equal_incremental_frames(renderer):
     from computeraytracer_amd.scenes_synth import mesh10k
     ps = mesh10k(480, 270)
