@@ -334,6 +334,7 @@ int upload_geometry(crt_ctx *c, int mode)
     if (nn4) HIPCHK(c, hipMemcpy(c->d_nodes4.p, c->bvh4.nodes.data(), nn4 * sizeof(float4), hipMemcpyHostToDevice));
     c->sc.nodes4 = c->d_nodes4.p;
     c->sc.root4 = c->bvh4.root;
+    c->sc.n_nodes4 = c->bvh4.n_inner;
     c->bvh4q = Bvh4Q();
     c->sc.nodes4q = nullptr;
     if (c->quantize && c->bvh4.n_inner) quantize_bvh4(c->bvh4, c->bvh4q);
@@ -355,7 +356,7 @@ int upload_geometry(crt_ctx *c, int mode)
 // ---------------------------------------------------------------- wavefront driver
 int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
 {
-    if (c->w_list_ext.n < 2 * list_elems) { HIPCHK(c, c->w_list_ext.alloc(2 * list_elems)); HIPCHK(c, c->w_list_sh.alloc(2 * list_elems)); }
+    if (c->w_list_ext.n < 8 * list_elems) HIPCHK(c, c->w_list_ext.alloc(8 * list_elems));   // [2 parities][4 classes]
     if (c->w_misc.n < P) {
         HIPCHK(c, c->w_ray_o.alloc(P)); HIPCHK(c, c->w_ray_d.alloc(P)); HIPCHK(c, c->w_sh_d.alloc(P));
         HIPCHK(c, c->w_beta.alloc(P)); HIPCHK(c, c->w_radiance.alloc(P)); HIPCHK(c, c->w_nee.alloc(P));
@@ -407,8 +408,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
     W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
     W.hit = c->w_hit.p; W.vis = c->w_vis.p;
-    W.list_ext[0] = c->w_list_ext.p; W.list_ext[1] = c->w_list_ext.p + (size_t)list_cap * kWfShards;
-    W.list_sh[0] = c->w_list_sh.p; W.list_sh[1] = c->w_list_sh.p + (size_t)list_cap * kWfShards;
+    for (int b = 0; b < 2; b++) for (int k = 0; k < 4; k++) W.list[b][k] = c->w_list_ext.p + (size_t)(b * 4 + k) * list_cap * kWfShards;
     W.staging = c->w_staging.p; W.ctl = c->w_ctl.p;
     W.P = P; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
     W.band = c->band; W.stride = c->stride; W.phase = c->phase;
@@ -467,8 +467,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             const unsigned long long size = lo < work_total ? std::min<unsigned long long>(work_per_shard, work_total - lo) : 0;
             if (hc->work[sidx].cur < size) work_left = true;
             const WfShard &sh = hc->shard[(it_end[cur] - 1) & 3u][sidx];
-            rays += (unsigned long long)sh.n_ext + sh.n_sh;
-            bound = std::max(bound, std::max(sh.n_ext, sh.n_sh));
+            for (int k = 0; k < 4; k++) { rays += sh.n[k]; bound = std::max(bound, sh.n[k]); }
         }
         if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] it %u rays %llu work_left %d bound %u\n", it_end[cur], rays, (int)work_left, bound);
         if (!work_left && rays == 0) break;                     // every slot alive after a shade pass lists a ray

@@ -242,6 +242,32 @@ void collapse_bvh4(const Bvh &b2, Bvh4 &out)
     out.nodes.assign((size_t)std::max<uint32_t>(b2.n_inner / 2 + 1, 1) * kNode4Floats, 0.0f);
     out.root = collapse_rec(b2, b2.root, out, 0);
     out.nodes.resize((size_t)std::max<uint32_t>(out.n_inner, 1) * kNode4Floats);
+    // Renumber breadth-first: the top levels become nodes [0, N) (cached in LDS by the traversal
+    // kernel) and siblings' subtrees sit near each other.
+    if (out.root >= 0 && out.n_inner > 1) {
+        std::vector<int32_t> order; order.reserve(out.n_inner);      // order[new] = old
+        std::vector<int32_t> newid(out.n_inner, -1);
+        order.push_back(out.root); newid[out.root] = 0;
+        for (size_t head = 0; head < order.size(); head++) {
+            const float *nd = &out.nodes[(size_t)order[head] * kNode4Floats];
+            for (int i = 0; i < 4; i++) {
+                int32_t r; std::memcpy(&r, &nd[24 + i], 4);
+                if (nd[i] < 3.0e38f && r >= 0 && newid[r] < 0) { newid[r] = (int32_t)order.size(); order.push_back(r); }
+            }
+        }
+        std::vector<float> nn(out.nodes.size());
+        for (size_t k = 0; k < order.size(); k++) {
+            const float *src = &out.nodes[(size_t)order[k] * kNode4Floats];
+            float *dst = &nn[k * kNode4Floats];
+            std::memcpy(dst, src, kNode4Floats * sizeof(float));
+            for (int i = 0; i < 4; i++) {
+                int32_t r; std::memcpy(&r, &src[24 + i], 4);
+                if (src[i] < 3.0e38f && r >= 0) { r = newid[r]; std::memcpy(&dst[24 + i], &r, 4); }
+            }
+        }
+        out.nodes.swap(nn);
+        out.root = 0;
+    }
 }
 
 

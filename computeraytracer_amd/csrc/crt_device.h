@@ -40,6 +40,7 @@ struct DevScene {
     uint32_t nprim;
     int32_t root;
     int32_t root4;
+    uint32_t n_nodes4;
     uint32_t nspectra;
     uint32_t nlight;
     float hit_pad;
@@ -72,7 +73,7 @@ struct TraceParams {
 //   misc    (work id, flags, last_bounce_pdf bits, etaScale bits)
 //   hit     (t, hit slot bits)            written by the trace kernel for extension rays
 //   vis     in: light primitive index, out: 1 = light visible    (shadow rays)
-//   list_ext / list_sh                    slots with an active ray this iteration (ballot/popc compacted)
+//   list[parity][class]                   slots with an active ray this iteration (ballot/popc compacted)
 //   staging (xyz, -) per (sample, pixel)  finished samples, summed in sample order by k_wf_resolve
 constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
 constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
@@ -83,7 +84,7 @@ constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits
 // the ray lists; traversal waves and re-arming waves pick a non-empty shard with one
 // wave-wide load + ballot.
 constexpr uint32_t kWfShards = 64;
-struct WfShard { uint32_t n_ext, n_sh, cur, pad[29]; };     // rays listed by shade / fetch cursor of trace
+struct WfShard { uint32_t n[4], cur, pad[27]; };              // rays listed by shade per class / fetch cursor of trace
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
@@ -98,7 +99,7 @@ struct WfParams {
     uint4 *rng, *misc;
     float2 *hit;
     uint32_t *vis;
-    uint32_t *list_ext[2], *list_sh[2];   // double-buffered by iteration parity
+    uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
     float4 *staging;
     WfCtl *ctl;
     uint32_t P;                      // pool size (slots)

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     WfCtl *ctl = P.ctl;
     if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
         WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
-        nx.n_ext = 0; nx.n_sh = 0; nx.cur = 0;
+        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
     }
     uint32_t slot, my_shard;
     bool in_pool, via_shadow_list = false;
@@ -113,19 +113,18 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         in_pool = slot < P.P;
     } else {
         // Tail mode (no work left, few paths alive): every alive slot listed a ray last iteration,
-        // so walk those lists instead of the whole pool.  Per shard: threads [0,bound) take the
-        // extension list, [bound,2*bound) the shadow list (only slots that are dying, i.e. not
-        // also in the extension list).
-        const uint32_t bps = (2u * P.tail_bound + (uint32_t)CRT_WF_SHADE_BLOCK - 1u) / (uint32_t)CRT_WF_SHADE_BLOCK;
+        // so walk those lists instead of the whole pool.  Per shard: threads [c*bound,(c+1)*bound)
+        // take list class c; shadow-class entries only count for slots that are dying, i.e. not
+        // also in an extension list.
+        const uint32_t bps = (4u * P.tail_bound + (uint32_t)CRT_WF_SHADE_BLOCK - 1u) / (uint32_t)CRT_WF_SHADE_BLOCK;
         my_shard = blockIdx.x / bps;
         const uint32_t j = (blockIdx.x % bps) * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
         const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
         const size_t region = (size_t)my_shard * P.list_cap;
         slot = 0; in_pool = false;
-        if (j < P.tail_bound) {
-            if (j < pv.n_ext) { slot = P.list_ext[lbuf ^ 1u][region + j]; in_pool = true; }
-        } else if (j - P.tail_bound < pv.n_sh && j < 2u * P.tail_bound) {
-            slot = P.list_sh[lbuf ^ 1u][region + (j - P.tail_bound)]; in_pool = true; via_shadow_list = true;
+        const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
+        if (cls < 4u && e < pv.n[cls]) {
+            slot = P.list[lbuf ^ 1u][cls][region + e]; in_pool = true; via_shadow_list = cls >= 2u;
         }
     }
     uint32_t c_rays = 0, c_bounces = 0, c_shadow = 0, c_hits = 0, c_paths = 0, c_prims = 0, c_walk = 0;
@@ -146,6 +145,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     if (via_shadow_list && !(R.flags & kWfDying)) in_pool = false;   // reached through its extension ray instead
     bool alive = in_pool && (R.flags & kWfAlive);
     bool emit_ext = false, emit_sh = false;
+    bool ext_primary = false, sh_primary = false;     // ray classes: camera ray / shadow ray of a camera-ray hit
     bool finished = false;
     // the hit primitive's whole record, also in one batch (valid only for an alive slot with a hit)
     const uint32_t h_slot = f_bits(h.y);
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                             P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};
                             P.vis[slot] = include;
                             emit_sh = true;
+                            sh_primary = depth == 0u;
                             R.flags |= kWfShadow;
                             if (COUNT) c_walk++;
                         }
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                     R.flags = kWfAlive | (lambda << kWfLambdaShift);
                     alive = true;
                     emit_ext = true;
+                    ext_primary = true;
                     emit_sh = false;
                     if (COUNT) { c_rays++; c_walk++; }
                 }
@@ -425,17 +427,25 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     }
     {
         const uint32_t lane = lane_id();
-        const unsigned long long me = __ballot(emit_ext), ms = __ballot(emit_sh);
+        // Four ray classes keep like with like in the traversal kernel: camera rays (coherent),
+        // bounce rays, shadow rays of camera-ray hits (coherent origins), other shadow rays.
+        const bool cl0 = emit_ext && ext_primary, cl1 = emit_ext && !ext_primary;
+        const bool cl2 = emit_sh && sh_primary, cl3 = emit_sh && !sh_primary;
+        const unsigned long long m0 = __ballot(cl0), m1 = __ballot(cl1), m2 = __ballot(cl2), m3 = __ballot(cl3);
         WfShard &sh = ctl->shard[ring][my_shard];
-        uint32_t be = 0, bs = 0;
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (lane == 0) {
-            if (me) be = atomicAdd(&sh.n_ext, (uint32_t)__popcll(me));
-            if (ms) bs = atomicAdd(&sh.n_sh, (uint32_t)__popcll(ms));
+            if (m0) b0 = atomicAdd(&sh.n[0], (uint32_t)__popcll(m0));
+            if (m1) b1 = atomicAdd(&sh.n[1], (uint32_t)__popcll(m1));
+            if (m2) b2 = atomicAdd(&sh.n[2], (uint32_t)__popcll(m2));
+            if (m3) b3 = atomicAdd(&sh.n[3], (uint32_t)__popcll(m3));
         }
-        be = __shfl(be, 0, 64); bs = __shfl(bs, 0, 64);
+        b0 = __shfl(b0, 0, 64); b1 = __shfl(b1, 0, 64); b2 = __shfl(b2, 0, 64); b3 = __shfl(b3, 0, 64);
         const size_t region = (size_t)my_shard * P.list_cap;
-        if (emit_ext) P.list_ext[lbuf][region + be + prefix_popc(me, lane)] = slot;
-        if (emit_sh) P.list_sh[lbuf][region + bs + prefix_popc(ms, lane)] = slot;
+        if (cl0) P.list[lbuf][0][region + b0 + prefix_popc(m0, lane)] = slot;
+        if (cl1) P.list[lbuf][1][region + b1 + prefix_popc(m1, lane)] = slot;
+        if (cl2) P.list[lbuf][2][region + b2 + prefix_popc(m2, lane)] = slot;
+        if (cl3) P.list[lbuf][3][region + b3 + prefix_popc(m3, lane)] = slot;
     }
     if (COUNT) {
         wave_add(ctl->counters + CRT_CNT_RAYS, c_rays);
@@ -480,7 +490,7 @@ __device__ __forceinline__ void tri_test(const float4 A, const float4 B, const f
 }
 
 // Persistent waves.  A wave owns a chunk of one shard's ray list at a time; entry i of a shard:
-// i < n_ext -> extension ray of slot list_ext[i]; otherwise shadow ray of slot list_sh[i - n_ext].
+// entries of the four class lists in order (camera rays, bounce rays, shadow rays of camera hits, shadow rays).
 // Traversal is "while-while": a bounded run of inner-node steps (lanes that reach a leaf wait,
 // cheaply), then one leaf step for every lane that has one -- so the expensive primitive tests
 // run with most lanes on.
@@ -501,8 +511,10 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     const float4 *__restrict__ g_sh_d = P.sh_d;
     uint32_t *__restrict__ g_vis = P.vis;
     float2 *__restrict__ g_hit = P.hit;
-    const uint32_t *__restrict__ list_ext = P.list_ext[it & 1u];
-    const uint32_t *__restrict__ list_sh = P.list_sh[it & 1u];
+    const uint32_t *__restrict__ list0 = P.list[it & 1u][0];
+    const uint32_t *__restrict__ list1 = P.list[it & 1u][1];
+    const uint32_t *__restrict__ list2 = P.list[it & 1u][2];
+    const uint32_t *__restrict__ list3 = P.list[it & 1u][3];
     const float hit_pad = P.sc.hit_pad;
     const int root = CRT_WF_BVH4 ? P.sc.root4 : P.sc.root;
     int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
@@ -517,12 +529,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     const float t_min = 0.001f;
 
     // wave-uniform fetch state: current shard, its ext count, the reserved chunk [pos,end)
-    uint32_t cur_shard = blockIdx.x % kWfShards, sh_n_ext = 0, sh_total = 0;
+    uint32_t cur_shard = blockIdx.x % kWfShards, sh_e0 = 0, sh_e1 = 0, sh_e2 = 0, sh_total = 0;   // class end offsets
     uint32_t chunk_pos = 0, chunk_end = 0;
     bool have_shard = false, exhausted = false;
     {   // start on this block's own shard (its counts are final: written by k_wf_shade); scan only when it is dry
         const WfShard &so = ctl->shard[ring][cur_shard];
-        sh_n_ext = so.n_ext; sh_total = sh_n_ext + so.n_sh;
+        sh_e0 = so.n[0]; sh_e1 = sh_e0 + so.n[1]; sh_e2 = sh_e1 + so.n[2]; sh_total = sh_e2 + so.n[3];
         have_shard = sh_total > 0u;
     }
     bool active = false;
@@ -554,15 +566,15 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                 // look at every shard at once: lane i loads shard i
                 if (COUNT) d_scans++;
                 const WfShard &sl = ctl->shard[ring][lane % kWfShards];
-                const uint32_t ne = sl.n_ext, tot = ne + sl.n_sh;
+                const uint32_t e0 = sl.n[0], e1 = e0 + sl.n[1], e2 = e1 + sl.n[2], tot = e2 + sl.n[3];
                 const uint32_t cur_l = __hip_atomic_load(&sl.cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long avail = __ballot(cur_l < tot);
                 if (!avail) { exhausted = true; break; }
                 const uint32_t rot = cur_shard & 63u;
                 const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
                 cur_shard = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
-                sh_n_ext = __shfl(ne, (int)cur_shard, 64);
-                sh_total = __shfl(tot, (int)cur_shard, 64);
+                sh_e0 = __shfl(e0, (int)cur_shard, 64); sh_e1 = __shfl(e1, (int)cur_shard, 64);
+                sh_e2 = __shfl(e2, (int)cur_shard, 64); sh_total = __shfl(tot, (int)cur_shard, 64);
                 have_shard = true;
             }
             if (chunk_pos < chunk_end) {
@@ -572,8 +584,9 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                 if (!active && my < give) {
                     const uint32_t idx = chunk_pos + my;
                     const size_t region = (size_t)cur_shard * P.list_cap;
-                    shadow = idx >= sh_n_ext;
-                    slot = shadow ? list_sh[region + (idx - sh_n_ext)] : list_ext[region + idx];
+                    shadow = idx >= sh_e1;
+                    slot = idx < sh_e0 ? list0[region + idx] : idx < sh_e1 ? list1[region + (idx - sh_e0)]
+                         : idx < sh_e2 ? list2[region + (idx - sh_e1)] : list3[region + (idx - sh_e2)];
                     // set up the ray
                     const float4 ro = g_ray_o[slot];
                     o = xyz(ro); excl = f_bits(ro.w);
@@ -795,7 +808,7 @@ __global__ void k_wf_init(const WfParams P)
         WfCtl *c = P.ctl;
         c->work[i].cur = 0;
         if (i == 0) c->work_done = 0;
-        for (int r = 0; r < 4; r++) { c->shard[r][i].n_ext = 0; c->shard[r][i].n_sh = 0; c->shard[r][i].cur = 0; }
+        for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; }
     }
 }
 
@@ -808,7 +821,7 @@ hipError_t wf_launch_init(const WfParams &P, hipStream_t s)
 
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
 {
-    const uint32_t bps = (2u * P.tail_bound + CRT_WF_SHADE_BLOCK - 1u) / CRT_WF_SHADE_BLOCK;
+    const uint32_t bps = (4u * P.tail_bound + CRT_WF_SHADE_BLOCK - 1u) / CRT_WF_SHADE_BLOCK;
     const dim3 gs(P.tail_bound ? kWfShards * bps : (P.P + CRT_WF_SHADE_BLOCK - 1) / CRT_WF_SHADE_BLOCK), bs(CRT_WF_SHADE_BLOCK);
     if (P.count) hipLaunchKernelGGL((k_wf_shade<true>), gs, bs, 0, s, P, it);
     else hipLaunchKernelGGL((k_wf_shade<false>), gs, bs, 0, s, P, it);

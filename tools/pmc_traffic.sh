@@ -1,0 +1,25 @@
+#!/bin/bash
+# HBM traffic of the current kernels: separate FETCH_SIZE / WRITE_SIZE passes (MI355X_MICROARCH.md: never mixed)
+out=$1; shift
+export TMPDIR=/tmp
+mkdir -p $out
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/p$i -- python3 tools/prof_workload.py "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for f in glob.glob('$out/p*/*/*counter_collection.csv'):
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'][:48]
+        agg[k][row['Counter_Name']] += float(row['Counter_Value'])
+        if row['Counter_Name'] == 'FETCH_SIZE': n[k] += 1
+for k, d in agg.items():
+    if 'k_wf' not in k: continue
+    print(k, 'launches', n[k])
+    for c, v in sorted(d.items()): print('   %-16s %.6g' % (c, v))
+    if n[k]:
+        print('   per launch: FETCH_SIZE*2 (gfx950 wide-read correction) %.1f MB, WRITE_SIZE %.1f MB' % (d['FETCH_SIZE'] * 2 * 1024 / n[k] / 1e6, d['WRITE_SIZE'] * 1024 / n[k] / 1e6))
+PY
