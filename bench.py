@@ -49,12 +49,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # CRT_BENCH_BACKEND=gloo + CRT_BENCH_ONE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all
+    # ranks share cuda:0, strips gathered through host memory).  The measured configuration is RCCL.
+    backend = os.environ.get("CRT_BENCH_BACKEND", "nccl")
+    if os.environ.get("CRT_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from computeraytracer_amd import Renderer, scenes_synth
     from computeraytracer_amd.distributed import StripFrame
@@ -89,6 +97,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    full_check = os.environ.get("CRT_BENCH_CHECK") == "1"    # rehearsal: compare the gathered frame with a 1-GPU render
+
     r.reset()
     for _ in range(args.warmup):
         step()
@@ -104,6 +114,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     sf.gather(accum=True)      # final readout of the f32 XYZ accumulator (outside the timed steps)
+    if full_check and world > 1 and rank == 0:
+        acc_all, rgba_all = sf.image()
+        ref = Renderer(local_rank)
+        ref.upload(ps).build_accel("bvh2").frame((args.warmup + args.steps) * args.spp).sync()
+        same = bool((torch.from_numpy(ref.read_accum()).to(dev) == acc_all).all()) and \
+            bool((torch.from_numpy(ref.read_rgba8()).to(dev) == rgba_all).all())
+        print(f"[check] gathered frame identical to a single-GPU render: {same}", file=sys.stderr, flush=True)
+        ref.close()
+        if not same:
+            raise SystemExit("gathered frame differs from the single-GPU render")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
