@@ -12,9 +12,11 @@ b3..b8 of ComputeShader.wgsl:1-9:
     spectra     n x 301    main.js:334-378   (f64 lerp, then f32)
     cie         3 x 471    main.js:380-393
 
-Extension (not in the reference): ``objects.triangles`` -> category 2 records,
-v0 = data1, e1 = v1-v0 = data2, e2 = v2-v0 = data3, appended after the spheres
-with index = array position (same rule as main.js:124,133).
+Extensions (not in the reference): ``objects.triangles`` [{v0,v1,v2,...}] and
+``objects.meshes`` [{obj: "file.obj" | vertices+indices, scale, translate,
+emission, reflectance, type}] -> category 2 records, v0 = data1, e1 = v1-v0 =
+data2, e2 = v2-v0 = data3 (f32 subtraction of f32 vertices), appended after the
+spheres with index = array position (same rule as main.js:124,133).
 The JS twin of this file is host/sceneLoader.js; tests check both against the
 SHA-256 pins of SURVEY.md 8c and against each other.
 """
@@ -160,13 +162,55 @@ def lights_of(primitives: np.ndarray) -> np.ndarray:
     return sel
 
 
-def pack_scene(scene: dict, cie: np.ndarray | None = None) -> PackedScene:
+def parse_obj(text: str):
+    """Minimal Wavefront OBJ reader: `v x y z` and `f a b c ...` (1-based, negative = relative,
+    `a/b/c` forms accepted, polygons fan-triangulated).  Returns (vertices [n][3], triangles [m][3])."""
+    verts, tris = [], []
+    for line in text.splitlines():
+        t = line.split()
+        if not t or t[0].startswith("#"):
+            continue
+        if t[0] == "v" and len(t) >= 4:
+            verts.append([float(t[1]), float(t[2]), float(t[3])])
+        elif t[0] == "f" and len(t) >= 4:
+            idx = []
+            for w in t[1:]:
+                k = int(w.split("/")[0])
+                idx.append(k - 1 if k > 0 else len(verts) + k)
+            for j in range(1, len(idx) - 1):
+                tris.append([idx[0], idx[j], idx[j + 1]])
+    return verts, tris
+
+
+def expand_meshes(scene: dict, base_dir: str | None = None) -> list:
+    """objects.meshes -> list of triangle dicts (vertex = v * scale + translate, in doubles)."""
+    out = []
+    for m in scene.get("objects", {}).get("meshes", []):
+        if "obj" in m:
+            path = m["obj"] if os.path.isabs(m["obj"]) else os.path.join(base_dir or SCENES_DIR, m["obj"])
+            with open(path) as f:
+                verts, tris = parse_obj(f.read())
+        else:
+            verts = m["vertices"]
+            flat = m["indices"]
+            tris = [flat[i:i + 3] for i in range(0, len(flat), 3)] if flat and not isinstance(flat[0], (list, tuple)) else flat
+        sc = m.get("scale", 1.0)
+        sc = [sc, sc, sc] if not isinstance(sc, (list, tuple)) else sc
+        tr = m.get("translate", [0.0, 0.0, 0.0])
+        P = [[v[0] * sc[0] + tr[0], v[1] * sc[1] + tr[1], v[2] * sc[2] + tr[2]] for v in verts]
+        for a, b, c in tris:
+            out.append({"v0": P[a], "v1": P[b], "v2": P[c], "emission": m["emission"],
+                        "reflectance": m["reflectance"], "type": m["type"]})
+    return out
+
+
+def pack_scene(scene: dict, cie: np.ndarray | None = None, base_dir: str | None = None) -> PackedScene:
     """Flatten (main.js:114-137) and pack (main.js:138-393) a scene dict in the
     reference's JSON schema."""
     objects = scene.get("objects", {})
     patches = objects.get("patches", [])
     spheres = objects.get("spheres", [])
-    tris = objects.get("triangles", [])
+    tris = list(objects.get("triangles", [])) + expand_meshes(scene, base_dir)
     spectra, key_index = resample_spectra(scene["spectra"])
 
     def names(items, key):

@@ -16,7 +16,7 @@ const num = (k, d) => (k in args ? Number(args[k]) : d);
 if (args['pack-only']) { // dump the packed host buffers (used by the packer parity test; needs no GPU)
   const scene = sceneLoader.loadScene(args.scene);
   if (args.width) scene.camera = { ...scene.camera, width: num('width'), height: num('height', num('width')) };
-  const p = sceneLoader.pack(scene);
+  const p = sceneLoader.pack(scene, undefined, args.scene ? require('path').dirname(require('path').resolve(args.scene)) : undefined);
   const pre = args['pack-only'];
   fs.writeFileSync(`${pre}.primitives.bin`, Buffer.from(p.primitives));
   fs.writeFileSync(`${pre}.patches.bin`, Buffer.from(p.patches));

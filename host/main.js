@@ -28,7 +28,7 @@ function Main(options = {}) {
   const a = loadAddon();
   const scene = options.scene || sceneLoader.loadScene(options.sceneFile);
   if (options.width) scene.camera = { ...scene.camera, width: options.width, height: options.height || options.width };
-  const packed = sceneLoader.pack(scene, options.cie);
+  const packed = sceneLoader.pack(scene, options.cie, options.sceneFile ? path.dirname(path.resolve(options.sceneFile)) : undefined);
   const { width, height } = packed;
 
   const device = a.create(options.device || 0);

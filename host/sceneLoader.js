@@ -11,7 +11,8 @@
  *   patches     n x 64 B  main.js:138-209   camera  16 f32    main.js:313-324
  *   spectra     n x 301   main.js:334-378   cie     3 x 471   main.js:380-393
  *
- * Extension: objects.triangles [{v0,v1,v2,emission,reflectance,type}] ->
+ * Extensions: objects.triangles [{v0,v1,v2,emission,reflectance,type}] and objects.meshes
+ * [{obj: 'file.obj' | vertices+indices, scale, translate, emission, reflectance, type}] ->
  * category 2 records (v0, v1-v0, v2-v0), appended after the spheres.
  * The Python twin is computeraytracer_amd/scene.py.
  */
@@ -51,13 +52,49 @@ function resampleSpectra(spectra) {
   return { table, keyIndex };
 }
 
+// Minimal Wavefront OBJ reader: `v x y z`, `f a b c ...` (1-based, negative = relative, a/b/c
+// forms accepted, polygons fan-triangulated).
+function parseObj(text) {
+  const verts = [], tris = [];
+  for (const line of text.split(/\r?\n/)) {
+    const t = line.trim().split(/\s+/);
+    if (!t[0] || t[0].startsWith('#')) continue;
+    if (t[0] === 'v' && t.length >= 4) verts.push([Number(t[1]), Number(t[2]), Number(t[3])]);
+    else if (t[0] === 'f' && t.length >= 4) {
+      const idx = t.slice(1).map((w) => { const k = parseInt(w.split('/')[0], 10); return k > 0 ? k - 1 : verts.length + k; });
+      for (let j = 1; j < idx.length - 1; j++) tris.push([idx[0], idx[j], idx[j + 1]]);
+    }
+  }
+  return { verts, tris };
+}
+
+// objects.meshes -> triangle objects (vertex = v * scale + translate, in doubles)
+function expandMeshes(scene, baseDir) {
+  const out = [];
+  for (const m of ((scene.objects || {}).meshes || [])) {
+    let verts, tris;
+    if (m.obj) {
+      const file = path.isAbsolute(m.obj) ? m.obj : path.join(baseDir || SCENES_DIR, m.obj);
+      ({ verts, tris } = parseObj(fs.readFileSync(file, 'utf8')));
+    } else {
+      verts = m.vertices;
+      tris = Array.isArray(m.indices[0]) ? m.indices : m.indices.reduce((a, v, i) => (i % 3 ? a[a.length - 1].push(v) : a.push([v]), a), []);
+    }
+    const sc = Array.isArray(m.scale) ? m.scale : [m.scale === undefined ? 1 : m.scale, m.scale === undefined ? 1 : m.scale, m.scale === undefined ? 1 : m.scale];
+    const tr = m.translate || [0, 0, 0];
+    const P = verts.map((v) => [v[0] * sc[0] + tr[0], v[1] * sc[1] + tr[1], v[2] * sc[2] + tr[2]]);
+    for (const [a, b, c] of tris) out.push({ v0: P[a], v1: P[b], v2: P[c], emission: m.emission, reflectance: m.reflectance, type: m.type });
+  }
+  return out;
+}
+
 // main.js:114-137: patches then spheres (then triangles); index = array position
-function flatten(scene) {
+function flatten(scene, baseDir) {
   const objects = scene.objects || {};
   const primitives = [];
   (objects.patches || []).forEach((p) => primitives.push({ ...p, index: primitives.length, category: 'patch' }));
   (objects.spheres || []).forEach((s) => primitives.push({ ...s, index: primitives.length, category: 'sphere' }));
-  (objects.triangles || []).forEach((t) => primitives.push({ ...t, index: primitives.length, category: 'triangle' }));
+  (objects.triangles || []).concat(expandMeshes(scene, baseDir)).forEach((t) => primitives.push({ ...t, index: primitives.length, category: 'triangle' }));
   return primitives;
 }
 
@@ -79,8 +116,8 @@ function loadCie(file) {
   return new Float32Array([...X, ...Y, ...Z]); // main.js:382
 }
 
-function pack(scene, cie) {
-  const prims = flatten(scene);
+function pack(scene, cie, baseDir) {
+  const prims = flatten(scene, baseDir);
   const { table: spectra, keyIndex } = resampleSpectra(scene.spectra);
   const idx = (name) => {
     if (!(name in keyIndex)) throw new Error(`unknown spectrum '${name}'`);
@@ -131,4 +168,4 @@ function loadScene(file) {
   return JSON.parse(fs.readFileSync(file || path.join(SCENES_DIR, 'cornell_box.json'), 'utf8'));
 }
 
-module.exports = { loadScene, loadCie, flatten, pack, resampleSpectra, sampleSpectrum, SCENES_DIR, TYPE_INDEX };
+module.exports = { loadScene, loadCie, flatten, pack, parseObj, expandMeshes, resampleSpectra, sampleSpectrum, SCENES_DIR, TYPE_INDEX };

@@ -327,6 +327,29 @@ def test_one_sample_per_pixel_and_tiny_tiles(renderer, orc):
     assert acc.size == 0
 
 
+def test_mesh_scene_and_python_cli(renderer, orc, tmp_path):
+    """OBJ mesh + glass sphere scene (scenes/cornell_mesh.json) vs the oracle; CLI writes PNG + checkpoint."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from computeraytracer_amd import image, scene as S
+    path = os.path.join(ROOT, "scenes", "cornell_mesh.json")
+    sc = S.load_scene(path)
+    sc["camera"]["width"], sc["camera"]["height"] = 96, 96
+    ps = S.pack_scene(sc, base_dir=os.path.join(ROOT, "scenes"))
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(6)
+    acc, rgba = render(renderer, ps, 6)
+    assert_same_image(acc, rgba, acc_o, rgba_o)
+    ck = str(tmp_path / "ck.npz")
+    for spp in (2, 4):                               # 2 samples, then resume for 4 more = the 6 above
+        subprocess.run([sys.executable, "-m", "computeraytracer_amd", "--scene", path, "--width", "96", "--height", "96",
+                        "--spp", str(spp), "--out", str(tmp_path / "o.png"), "--checkpoint", ck], cwd=ROOT, check=True,
+                       capture_output=True)
+    d = np.load(ck)
+    assert int(d["sample"]) == 6 and np.array_equal(bits(d["accum"]), bits(acc))
+    assert (tmp_path / "o.png").read_bytes()[:4] == b"\x89PNG"
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_errors_are_reported_not_fatal():
     from computeraytracer_amd import Renderer, cornell, scene as S

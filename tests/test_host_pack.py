@@ -83,3 +83,47 @@ def test_addon_loads_and_throws_without_gpu():
     out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, check=True).stdout
     if not torch.cuda.is_available():
         assert "threw:" in out and "no CPU fallback" in out
+
+
+def test_obj_parser_and_mesh_expansion(tmp_path):
+    from computeraytracer_amd import scene as S
+    verts, tris = S.parse_obj("# c\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -4 -3 -1\n")
+    assert len(verts) == 4 and tris == [[0, 1, 2], [0, 2, 3], [0, 1, 3]]
+    sc = S.load_scene()
+    sc["objects"]["meshes"] = [{"vertices": verts, "indices": [0, 1, 2, 0, 2, 3], "scale": 2.0, "translate": [1, 2, 3],
+                                "emission": "dark", "reflectance": "red", "type": "diffuse"}]
+    ps = S.pack_scene(sc)
+    t = ps.primitives[-2:]
+    assert list(t["category"]) == [2, 2] and list(t["data1"][0]) == [1, 2, 3] and list(t["data2"][0]) == [2, 0, 0]
+    assert list(t["data3"][1]) == [0, 2, 0] and list(t["data4"][1]) == [4, 2, 0, 19]
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_mesh_scene_js_equals_python(tmp_path):
+    from computeraytracer_amd import scene as S
+    path = os.path.join(ROOT, "scenes", "cornell_mesh.json")
+    subprocess.run([NODE, os.path.join(ROOT, "host", "index.js"), "--scene", path, "--width", "80", "--height", "48",
+                    "--pack-only", str(tmp_path / "js")], capture_output=True, text=True, check=True)
+    sc = S.load_scene(path)
+    sc["camera"]["width"], sc["camera"]["height"] = 80, 48
+    ps = S.pack_scene(sc, base_dir=os.path.join(ROOT, "scenes"))
+    assert len(ps.primitives) == 6 + 1 + 8
+    for name, arr in [("primitives", ps.primitives), ("lights", ps.lights), ("camera", ps.camera), ("spectra", ps.spectra)]:
+        assert (tmp_path / f"js.{name}.bin").read_bytes() == arr.tobytes(), name
+
+
+def test_image_writers(tmp_path):
+    import struct
+    import zlib
+    from computeraytracer_amd import image
+    rgba = (np.arange(5 * 7 * 4) % 251).astype(np.uint8).reshape(5, 7, 4)
+    image.write_ppm(str(tmp_path / "a.ppm"), rgba)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n7 5\n255\n") and raw[11:] == rgba[..., :3].tobytes()
+    image.write_png(str(tmp_path / "a.png"), rgba)
+    png = (tmp_path / "a.png").read_bytes()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", png[16:24]) == (7, 5)
+    i = png.index(b"IDAT")
+    n = struct.unpack(">I", png[i - 4:i])[0]
+    rows = np.frombuffer(zlib.decompress(png[i + 4:i + 4 + n]), np.uint8).reshape(5, 1 + 7 * 4)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(5, 7, 4), rgba)
