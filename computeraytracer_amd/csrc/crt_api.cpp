@@ -119,15 +119,22 @@ struct crt_ctx {
     // wavefront pipeline (crt_wavefront.hip)
     int pipeline = 1;               // 1 = wavefront (default), 0 = v1 megakernel
     uint32_t wf_pool = 0;           // 0 = auto
-    uint32_t wf_waves_per_cu = 16;
+    uint32_t wf_waves_per_cu = 14;  // per pipe
     int num_cu = 0;
     DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging;
     DevBuf<uint4> w_rng, w_misc;
     DevBuf<float2> w_hit;
     DevBuf<uint32_t> w_vis, w_list_ext, w_list_sh;
-    DevBuf<WfCtl> w_ctl;
-    WfCtl *h_ctl[2] = {nullptr, nullptr};   // pinned, double-buffered status readbacks
-    hipEvent_t ev_ctl[2] = {nullptr, nullptr};
+    // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
+    static constexpr int kMaxPipes = 4;
+    int wf_pipes = 2;
+    DevBuf<WfCtl> w_ctl[kMaxPipes];
+    DevBuf<WfWorkQ> w_wq;
+    WfWorkQ *h_wq[2] = {nullptr, nullptr};                 // pinned
+    WfCtl *h_ctl[kMaxPipes][2] = {};                       // pinned, double-buffered status readbacks
+    hipEvent_t ev_ctl[kMaxPipes][2] = {};
+    hipStream_t pipe_stream[kMaxPipes] = {};               // [0] unused: pipe 0 runs on the context's stream
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {};
     bool time_kernels = false;
     std::vector<hipEvent_t> kev;    // event pairs around k_wf_trace launches
     float last_trace_kernel_ms = 0.0f;
@@ -356,7 +363,7 @@ int upload_geometry(crt_ctx *c, int mode)
 // ---------------------------------------------------------------- wavefront driver
 int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
 {
-    if (c->w_list_ext.n < 8 * list_elems) HIPCHK(c, c->w_list_ext.alloc(8 * list_elems));   // [2 parities][4 classes]
+    if (c->w_list_ext.n < list_elems) HIPCHK(c, c->w_list_ext.alloc(list_elems));
     if (c->w_misc.n < P) {
         HIPCHK(c, c->w_ray_o.alloc(P)); HIPCHK(c, c->w_ray_d.alloc(P)); HIPCHK(c, c->w_sh_d.alloc(P));
         HIPCHK(c, c->w_beta.alloc(P)); HIPCHK(c, c->w_radiance.alloc(P)); HIPCHK(c, c->w_nee.alloc(P));
@@ -364,13 +371,21 @@ int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
         HIPCHK(c, c->w_vis.alloc(P));
     }
     if (c->w_staging.n < staging_elems) HIPCHK(c, c->w_staging.alloc(staging_elems));
-    if (!c->w_ctl.p) {
-        HIPCHK(c, c->w_ctl.alloc(1));
-        HIPCHK(c, hipMemset(c->w_ctl.p, 0, sizeof(WfCtl)));
-        for (int b = 0; b < 2; b++) {
-            HIPCHK(c, hipHostMalloc((void **)&c->h_ctl[b], sizeof(WfCtl), hipHostMallocDefault));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl[b], hipEventDisableTiming));
+    if (!c->w_wq.p) {
+        HIPCHK(c, c->w_wq.alloc(1));
+        HIPCHK(c, hipMemset(c->w_wq.p, 0, sizeof(WfWorkQ)));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
+            HIPCHK(c, c->w_ctl[p].alloc(1));
+            HIPCHK(c, hipMemset(c->w_ctl[p].p, 0, sizeof(WfCtl)));
+            for (int b = 0; b < 2; b++) {
+                HIPCHK(c, hipHostMalloc((void **)&c->h_ctl[p][b], sizeof(WfCtl), hipHostMallocDefault));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl[p][b], hipEventDisableTiming));
+            }
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[p], hipEventDisableTiming));
+            if (p > 0) HIPCHK(c, hipStreamCreateWithFlags(&c->pipe_stream[p], hipStreamNonBlocking));
         }
+        for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[b], sizeof(WfWorkQ), hipHostMallocDefault));
     }
     if (c->num_cu == 0) {
         hipDeviceProp_t prop;
@@ -378,11 +393,20 @@ int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     {   // deep-stack overflow area: 64 levels beyond the LDS part for every resident traversal lane
-        const size_t lanes = (size_t)c->num_cu * c->wf_waves_per_cu * 64;
+        const size_t lanes = (size_t)c->num_cu * c->wf_waves_per_cu * 64u * (size_t)std::max(1, c->wf_pipes);
         if (c->w_overflow.n < lanes * 64) HIPCHK(c, c->w_overflow.alloc(lanes * 64));
     }
     return CRT_OK;
 }
+
+// One shade->trace chain over its share of the pool.
+struct WfPipe {
+    WfParams W{};
+    hipStream_t stream = nullptr;
+    uint32_t it = 0, chunk = 4, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
+    int cur = 0;
+    bool done = false;
+};
 
 // One batch of n samples through the wavefront pipeline (asynchronous except for the small
 // control-block readbacks that decide when the pool has drained).
@@ -393,45 +417,64 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     const size_t npix = (size_t)c->tw * c->th;
     if (npix == 0 || n == 0) { c->sample += n; return CRT_OK; }
     const unsigned long long work_total = (unsigned long long)n * npix_padded;
-    uint32_t P = c->wf_pool ? c->wf_pool : (1u << 21);
+    uint32_t P = c->wf_pool ? c->wf_pool : (1u << 22);
     if ((unsigned long long)P > work_total) P = (uint32_t)work_total;
-    P = (P + 255u) & ~255u;
+    // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
+    // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
+    int K = std::max(1, std::min(c->wf_pipes, (int)crt_ctx::kMaxPipes));
+    if (P < (1u << 18)) K = 1;
+    const uint32_t Pp = ((P / (uint32_t)K) + 255u) & ~255u;       // slots per pipe
+    P = Pp * (uint32_t)K;
     // list capacity per shard: any shade block size >= 64 maps at most ceil(blocks/shards) blocks to a shard
-    const uint32_t list_cap = ((P / 64u + kWfShards - 1) / kWfShards) * 64u + 256u;
+    const uint32_t list_cap = ((Pp / 64u + kWfShards - 1) / kWfShards) * 64u + 256u;
     uint32_t work_per_shard = (uint32_t)((work_total + kWfShards - 1) / kWfShards);
     work_per_shard = (work_per_shard + 63u) & ~63u;
-    int rc = wf_ensure(c, P, (size_t)n * npix, (size_t)list_cap * kWfShards);
+    const size_t list_per_pipe = (size_t)8 * list_cap * kWfShards;                 // [2 parities][4 classes]
+    int rc = wf_ensure(c, P, (size_t)n * npix, list_per_pipe * (size_t)K);
     if (rc) return rc;
-
-    WfParams W{};
-    W.sc = c->sc;
-    W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
-    W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
-    W.hit = c->w_hit.p; W.vis = c->w_vis.p;
-    for (int b = 0; b < 2; b++) for (int k = 0; k < 4; k++) W.list[b][k] = c->w_list_ext.p + (size_t)(b * 4 + k) * list_cap * kWfShards;
-    W.staging = c->w_staging.p; W.ctl = c->w_ctl.p;
-    W.P = P; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
-    W.band = c->band; W.stride = c->stride; W.phase = c->phase;
-    W.tiles_x = tiles_x; W.tiles_y = tiles_y; W.npix_padded = npix_padded; W.work_total = work_total;
-    W.work_per_shard = work_per_shard; W.list_cap = list_cap;
-    W.first_sample = c->sample + 1; W.n_samples = n;
-    W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
-    W.count = c->counting ? 1u : 0u;
-    W.stack_overflow = c->w_overflow.p;
-    W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
     const uint32_t trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
 
-    HIPCHK(c, wf_launch_init(W, c->stream));
-    // Iterations are enqueued in chunks; after each chunk the small control block is copied back
+    WfPipe pipes[crt_ctx::kMaxPipes];
+    for (int p = 0; p < K; p++) {
+        WfParams &W = pipes[p].W;
+        W.sc = c->sc;
+        W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
+        W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
+        W.hit = c->w_hit.p; W.vis = c->w_vis.p;
+        for (int b = 0; b < 2; b++)
+            for (int k = 0; k < 4; k++)
+                W.list[b][k] = c->w_list_ext.p + list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * list_cap * kWfShards;
+        W.staging = c->w_staging.p; W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
+        W.slot_base = Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
+        W.P = Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
+        W.band = c->band; W.stride = c->stride; W.phase = c->phase;
+        W.tiles_x = tiles_x; W.tiles_y = tiles_y; W.npix_padded = npix_padded; W.work_total = work_total;
+        W.work_per_shard = work_per_shard; W.list_cap = list_cap;
+        W.first_sample = c->sample + 1; W.n_samples = n;
+        W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
+        W.count = c->counting ? 1u : 0u;
+        W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
+        W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * 64u;
+        pipes[p].stream = (p == 0) ? c->stream : c->pipe_stream[p];
+        pipes[p].blocks_now = trace_blocks;
+    }
+    // fork: pipe 0's init resets the shared work queue; the other streams start after it
+    HIPCHK(c, wf_launch_init(pipes[0].W, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int p = 1; p < K; p++) {
+        HIPCHK(c, hipStreamWaitEvent(pipes[p].stream, c->ev_fork, 0));
+        HIPCHK(c, wf_launch_init(pipes[p].W, pipes[p].stream));
+    }
+
+    // Iterations are enqueued in chunks; after each chunk the small control blocks are copied back
     // (asynchronously) so the host can tell when the pool has drained.  One chunk is always
     // enqueued AHEAD of the status being waited for, so the GPU never idles on the host; the
     // price is at most one chunk of empty iterations at the end.
-    uint32_t it = 0, chunk = 4, tail_bound = 0, blocks_now = trace_blocks;
-    uint32_t it_end[2] = {0, 0};
-    auto enqueue_chunk = [&](int buf) -> int {
-        W.tail_bound = tail_bound;
-        for (uint32_t k = 0; k < chunk; k++, it++) {
-            HIPCHK(c, wf_launch_shade(W, it, c->stream));
+    auto enqueue_chunk = [&](int p, int buf) -> int {
+        WfPipe &pp = pipes[p];
+        pp.W.tail_bound = pp.tail_bound;
+        for (uint32_t k = 0; k < pp.chunk; k++, pp.it++) {
+            HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
             if (c->time_kernels) {
                 size_t need = 2 * (size_t)(c->last_trace_kernel_launches + 1);
                 while (c->kev.size() < need) {
@@ -439,63 +482,81 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
                     HIPCHK(c, hipEventCreate(&e));
                     c->kev.push_back(e);
                 }
-                HIPCHK(c, hipEventRecord(c->kev[need - 2], c->stream));
+                HIPCHK(c, hipEventRecord(c->kev[need - 2], pp.stream));
             }
-            HIPCHK(c, wf_launch_trace(W, it, blocks_now, c->stream));
-            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], c->stream));
+            HIPCHK(c, wf_launch_trace(pp.W, pp.it, pp.blocks_now, pp.stream));
+            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], pp.stream));
             c->last_trace_kernel_launches++;
             c->last_launches += 2;
         }
-        it_end[buf] = it;
-        HIPCHK(c, hipMemcpyAsync(c->h_ctl[buf], c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev_ctl[buf], c->stream));
+        pp.it_end[buf] = pp.it;
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl[p][buf], pp.W.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, pp.stream));
+        if (p == 0) HIPCHK(c, hipMemcpyAsync(c->h_wq[buf], c->w_wq.p, sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
+        HIPCHK(c, hipEventRecord(c->ev_ctl[p][buf], pp.stream));
         return CRT_OK;
     };
-    int cur = 0;
-    rc = enqueue_chunk(cur);
-    if (rc) return rc;
-    for (;;) {
-        rc = enqueue_chunk(cur ^ 1);                           // speculative: keeps the GPU busy during the wait
-        if (rc) return rc;
-        HIPCHK(c, hipEventSynchronize(c->ev_ctl[cur]));
-        const WfCtl *hc = c->h_ctl[cur];
-        bool work_left = false;
-        unsigned long long rays = 0;
-        uint32_t bound = 0;
-        for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-            const unsigned long long lo = (unsigned long long)sidx * work_per_shard;
-            const unsigned long long size = lo < work_total ? std::min<unsigned long long>(work_per_shard, work_total - lo) : 0;
-            if (hc->work[sidx].cur < size) work_left = true;
-            const WfShard &sh = hc->shard[(it_end[cur] - 1) & 3u][sidx];
-            for (int k = 0; k < 4; k++) { rays += sh.n[k]; bound = std::max(bound, sh.n[k]); }
-        }
-        if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] it %u rays %llu work_left %d bound %u\n", it_end[cur], rays, (int)work_left, bound);
-        if (!work_left && rays == 0) break;                     // every slot alive after a shade pass lists a ray
-        if (!work_left) {
-            // The tail: no path can start any more, so ray counts only shrink from here.  Once few
-            // are left, shade walks the ray lists instead of the whole pool and the grids shrink.
-            if (rays < (unsigned long long)P / 4u) {
-                tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
-                blocks_now = (uint32_t)std::min<unsigned long long>(trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
+    for (int p = 0; p < K; p++) { rc = enqueue_chunk(p, 0); if (rc) return rc; }
+    int active = K;
+    bool work_left = true;
+    while (active > 0) {
+        for (int p = 0; p < K; p++)
+            if (!pipes[p].done) { rc = enqueue_chunk(p, pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
+        for (int p = 0; p < K; p++) {
+            WfPipe &pp = pipes[p];
+            if (pp.done) continue;
+            HIPCHK(c, hipEventSynchronize(c->ev_ctl[p][pp.cur]));
+            if (p == 0) {
+                bool left = false;
+                for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
+                    const unsigned long long lo = (unsigned long long)sidx * work_per_shard;
+                    const unsigned long long size = lo < work_total ? std::min<unsigned long long>(work_per_shard, work_total - lo) : 0;
+                    if (c->h_wq[pp.cur]->work[sidx].cur < size) left = true;
+                }
+                work_left = left;                                // monotone: once false it stays false
             }
+            const WfCtl *hc = c->h_ctl[p][pp.cur];
+            unsigned long long rays = 0;
+            uint32_t bound = 0;
+            for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
+                const WfShard &sh = hc->shard[(pp.it_end[pp.cur] - 1) & 3u][sidx];
+                for (int k = 0; k < 4; k++) { rays += sh.n[k]; bound = std::max(bound, sh.n[k]); }
+            }
+            if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu work_left %d bound %u\n", p, pp.it_end[pp.cur], rays, (int)work_left, bound);
+            // pipe 0's view of the queue can lag the others by a chunk; a pipe with no rays while work
+            // may be left simply keeps going (its dead slots re-arm as soon as they see work)
+            if (!work_left && rays == 0) { pp.done = true; active--; continue; }   // every alive slot lists a ray
+            if (!work_left && rays < (unsigned long long)Pp / 4u) {
+                // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
+                // the ray lists instead of the whole pool and the grids shrink.
+                pp.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
+                pp.blocks_now = (uint32_t)std::min<unsigned long long>(trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
+            }
+            if (pp.it > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+            pp.cur ^= 1;
         }
-        if (it > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
-        cur ^= 1;
     }
-    c->last_iterations += it;
+    // join: the resolve pass on the context's stream waits for every pipe
+    for (int p = 1; p < K; p++) {
+        HIPCHK(c, hipEventRecord(c->ev_join[p], pipes[p].stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+    }
+    for (int p = 0; p < K; p++) c->last_iterations += pipes[p].it;
     if (c->counting) {
-        // fold the pipeline's counters into the context's
-        HIPCHK(c, hipMemcpyAsync(c->h_ctl[0], c->w_ctl.p, sizeof(WfCtl), hipMemcpyDeviceToHost, c->stream));
+        // fold the pipes' counters into the context's
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        unsigned long long cur[CRT_NCOUNTERS];
-        HIPCHK(c, hipMemcpy(cur, c->d_counters.p, sizeof cur, hipMemcpyDeviceToHost));
-        for (int k = 0; k < CRT_NCOUNTERS; k++) cur[k] += c->h_ctl[0]->counters[k];
-        for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl[0]->counters[8 + k];
-        HIPCHK(c, hipMemcpy(c->d_counters.p, cur, sizeof cur, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemsetAsync(&c->w_ctl.p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV, c->stream));
+        unsigned long long tot[CRT_NCOUNTERS];
+        HIPCHK(c, hipMemcpy(tot, c->d_counters.p, sizeof tot, hipMemcpyDeviceToHost));
+        for (int p = 0; p < K; p++) {
+            HIPCHK(c, hipMemcpy(c->h_ctl[p][0], c->w_ctl[p].p, sizeof(WfCtl), hipMemcpyDeviceToHost));
+            for (int k = 0; k < CRT_NCOUNTERS; k++) tot[k] += c->h_ctl[p][0]->counters[k];
+            for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl[p][0]->counters[8 + k];
+            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
+        }
+        HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
     }
     c->sample += n;
-    HIPCHK(c, wf_launch_resolve(W, c->sample, c->stream));
+    WfParams R = pipes[0].W;
+    HIPCHK(c, wf_launch_resolve(R, c->sample, c->stream));
     c->last_launches += 2;
     return CRT_OK;
 }
@@ -545,11 +606,18 @@ void crt_destroy(crt_ctx *c)
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); c->w_staging.release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
-    c->w_vis.release(); c->w_list_ext.release(); c->w_list_sh.release(); c->w_ctl.release();
-    for (int b = 0; b < 2; b++) {
-        if (c->h_ctl[b]) (void)hipHostFree(c->h_ctl[b]);
-        if (c->ev_ctl[b]) (void)hipEventDestroy(c->ev_ctl[b]);
+    c->w_vis.release(); c->w_list_ext.release(); c->w_list_sh.release(); c->w_wq.release();
+    for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
+        c->w_ctl[p].release();
+        for (int b = 0; b < 2; b++) {
+            if (c->h_ctl[p][b]) (void)hipHostFree(c->h_ctl[p][b]);
+            if (c->ev_ctl[p][b]) (void)hipEventDestroy(c->ev_ctl[p][b]);
+        }
+        if (c->pipe_stream[p]) (void)hipStreamDestroy(c->pipe_stream[p]);
+        if (c->ev_join[p]) (void)hipEventDestroy(c->ev_join[p]);
     }
+    for (int b = 0; b < 2; b++) if (c->h_wq[b]) (void)hipHostFree(c->h_wq[b]);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -903,6 +971,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
     if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
+    if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "time_kernels")) { c->time_kernels = value != 0; return CRT_OK; }

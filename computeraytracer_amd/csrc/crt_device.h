@@ -88,9 +88,13 @@ struct WfShard { uint32_t n[4], cur, pad[27]; };              // rays listed by 
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
+    unsigned long long counters[CRT_NCOUNTERS_DEV];
+};
+// The work queue is shared by the pipes of a context (two half-pools run on two streams so that
+// one half's streaming shade pass overlaps the other half's latency-bound traversal).
+struct WfWorkQ {
     WfWork work[kWfShards];
     uint32_t work_done, pad_[31];    // set once every work shard is exhausted (saves the scans)
-    unsigned long long counters[CRT_NCOUNTERS_DEV];
 };
 
 struct WfParams {
@@ -102,7 +106,10 @@ struct WfParams {
     uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
     float4 *staging;
     WfCtl *ctl;
-    uint32_t P;                      // pool size (slots)
+    WfWorkQ *wq;
+    uint32_t slot_base;              // this pipe's slots are [slot_base, slot_base + P)
+    uint32_t reset_wq;               // k_wf_init also resets the shared work queue
+    uint32_t P;                      // slots of this pipe
     uint32_t x0, y0, tw, th;         // tile rectangle (local buffer is tw x th)
     uint32_t band, stride, phase;    // row interleave: global y = y0 + (ly/band)*band*stride + phase*band + ly%band
     uint32_t tiles_x, tiles_y;

@@ -108,9 +108,10 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     uint32_t slot, my_shard;
     bool in_pool, via_shadow_list = false;
     if (P.tail_bound == 0u) {
-        slot = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
+        const uint32_t local = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
+        slot = P.slot_base + local;
         my_shard = blockIdx.x % kWfShards;
-        in_pool = slot < P.P;
+        in_pool = local < P.P;
     } else {
         // Tail mode (no work left, few paths alive): every alive slot listed a ray last iteration,
         // so walk those lists instead of the whole pool.  Per shard: threads [c*bound,(c+1)*bound)
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         const bool want0 = in_pool && !alive;
         bool want = want0;
         const uint32_t lane = lane_id();
-        const bool all_done = __hip_atomic_load(&ctl->work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        const bool all_done = __hip_atomic_load(&P.wq->work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         for (int attempt = 0; attempt < 3 && !all_done; attempt++) {
             const unsigned long long m = __ballot(want);
             if (!m) break;
@@ -345,14 +346,14 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                 // one uniform load of the own cursor: skip the atomic when this shard is already dry
                 const unsigned long long lo0 = (unsigned long long)my_shard * P.work_per_shard;
                 const unsigned long long hi0 = min(lo0 + (unsigned long long)P.work_per_shard, P.work_total);
-                const uint32_t cur0 = __hip_atomic_load(&ctl->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cur0 = __hip_atomic_load(&P.wq->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (hi0 <= lo0 || cur0 >= (uint32_t)(hi0 - lo0)) continue;
             } else {
                 // own shard ran dry: look at every cursor at once (lane i loads shard i) and move on
-                const uint32_t cur_l = __hip_atomic_load(&ctl->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cur_l = __hip_atomic_load(&P.wq->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long avail = __ballot(cur_l < size_l);
                 if (!avail) {                                        // every shard is exhausted
-                    if (lane == 0) __hip_atomic_store(&ctl->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(&P.wq->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 const uint32_t rot = my_shard & 63u;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
             }
             const uint32_t n = (uint32_t)__popcll(m);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctl->work[s_pick].cur, n);
+            if (lane == 0) base = atomicAdd(&P.wq->work[s_pick].cur, n);
             base = __shfl(base, 0, 64);
             const uint32_t size_s = __shfl(size_l, (int)s_pick, 64);
             const uint32_t got = base < size_s ? min(n, size_s - base) : 0u;
@@ -803,12 +804,14 @@ __global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t l
 __global__ void k_wf_init(const WfParams P)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < P.P) P.misc[i] = uint4{0, 0, 0, 0};
+    if (i < P.P) P.misc[P.slot_base + i] = uint4{0, 0, 0, 0};
     if (i < kWfShards) {
         WfCtl *c = P.ctl;
-        c->work[i].cur = 0;
-        if (i == 0) c->work_done = 0;
         for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; }
+        if (P.reset_wq) {
+            P.wq->work[i].cur = 0;
+            if (i == 0) P.wq->work_done = 0;
+        }
     }
 }
 
