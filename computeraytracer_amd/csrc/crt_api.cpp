@@ -28,6 +28,7 @@ hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out,
 hipError_t wf_launch_init(const WfParams &P, hipStream_t s);
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
+hipError_t wf_launch_finish(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
 }  // namespace crt
 
@@ -128,6 +129,7 @@ struct crt_ctx {
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
+    uint32_t wf_finish_at = 4096;   // rays left (per pipe) at which k_wf_finish takes over; 0 = never
     DevBuf<WfCtl> w_ctl[kMaxPipes];
     DevBuf<WfWorkQ> w_wq;
     WfWorkQ *h_wq[2] = {nullptr, nullptr};                 // pinned
@@ -417,13 +419,17 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     const size_t npix = (size_t)c->tw * c->th;
     if (npix == 0 || n == 0) { c->sample += n; return CRT_OK; }
     const unsigned long long work_total = (unsigned long long)n * npix_padded;
-    uint32_t P = c->wf_pool ? c->wf_pool : (1u << 22);
+    // pool: about 1/8 of the batch's paths in flight, between 1 M and 4 M slots (measured best on S2)
+    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 22, std::max<unsigned long long>(1u << 20, work_total / 8u));
     if ((unsigned long long)P > work_total) P = (uint32_t)work_total;
     // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
     // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
     int K = std::max(1, std::min(c->wf_pipes, (int)crt_ctx::kMaxPipes));
     if (P < (1u << 18)) K = 1;
-    const uint32_t Pp = ((P / (uint32_t)K) + 255u) & ~255u;       // slots per pipe
+    // slots per pipe: a whole number of shade blocks for every one of the 64 shards when possible
+    // (measured: a 1/8 strip takes 13.0 ms with such a pool and 15.1 ms with one 0.4 % smaller)
+    uint32_t Pp = P / (uint32_t)K;
+    Pp = Pp >= 16384u ? (Pp / 16384u) * 16384u : ((Pp + 255u) & ~255u);
     P = Pp * (uint32_t)K;
     // list capacity per shard: any shade block size >= 64 maps at most ceil(blocks/shards) blocks to a shard
     const uint32_t list_cap = ((Pp / 64u + kWfShards - 1) / kWfShards) * 64u + 256u;
@@ -497,7 +503,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     };
     for (int p = 0; p < K; p++) { rc = enqueue_chunk(p, 0); if (rc) return rc; }
     int active = K;
-    bool work_left = true;
+    bool work_left = true, serial = false;
     while (active > 0) {
         for (int p = 0; p < K; p++)
             if (!pipes[p].done) { rc = enqueue_chunk(p, pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
@@ -519,15 +525,41 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             uint32_t bound = 0;
             for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
                 const WfShard &sh = hc->shard[(pp.it_end[pp.cur] - 1) & 3u][sidx];
-                for (int k = 0; k < 4; k++) { rays += sh.n[k]; bound = std::max(bound, sh.n[k]); }
+                // per-shard bound for later iterations: slots never change shard and none are re-armed in the
+                // tail, so no list of a shard can ever grow beyond the slots alive in it now
+                uint32_t alive_here = 0;
+                for (int k = 0; k < 4; k++) { rays += sh.n[k]; alive_here += sh.n[k]; }
+                bound = std::max(bound, alive_here);
             }
             if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu work_left %d bound %u\n", p, pp.it_end[pp.cur], rays, (int)work_left, bound);
             // pipe 0's view of the queue can lag the others by a chunk; a pipe with no rays while work
             // may be left simply keeps going (its dead slots re-arm as soon as they see work)
             if (!work_left && rays == 0) { pp.done = true; active--; continue; }   // every alive slot lists a ray
-            if (!work_left && rays < (unsigned long long)Pp / 4u) {
+            if (!work_left && rays <= c->wf_finish_at && serial) {
+                // A few paths left: one kernel runs them to the end (ray counts only shrink from here, so
+                // `bound` also covers the chunk already enqueued ahead).
+                pp.W.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
+                HIPCHK(c, wf_launch_finish(pp.W, pp.it, pp.stream));
+                c->last_launches++;
+                pp.done = true; active--;
+                continue;
+            }
+            if (!work_left && rays < std::min<unsigned long long>((unsigned long long)Pp / 4u, 65536ull)) {
                 // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
                 // the ray lists instead of the whole pool and the grids shrink.
+                // From the first pipe that gets here on, every pipe continues on the context's stream:
+                // the tiny tail kernels of one pipe running concurrently with another pipe's kernels gave
+                // rare wrong pixels on MI355X (a few in 10^6, only with both conditions; root cause not
+                // pinned down, the overlap is worthless in the tail anyway).
+                if (!serial) {
+                    serial = true;
+                    for (int q = 1; q < K; q++) {
+                        if (pipes[q].stream == c->stream) continue;
+                        HIPCHK(c, hipEventRecord(c->ev_join[q], pipes[q].stream));
+                        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[q], 0));
+                        pipes[q].stream = c->stream;
+                    }
+                }
                 pp.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
                 pp.blocks_now = (uint32_t)std::min<unsigned long long>(trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
             }
@@ -537,6 +569,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     }
     // join: the resolve pass on the context's stream waits for every pipe
     for (int p = 1; p < K; p++) {
+        if (pipes[p].stream == c->stream) continue;
         HIPCHK(c, hipEventRecord(c->ev_join[p], pipes[p].stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
     }
@@ -971,6 +1004,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
     if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
+    if (!std::strcmp(name, "wf_finish_at")) { c->wf_finish_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }

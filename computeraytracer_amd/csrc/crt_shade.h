@@ -172,6 +172,7 @@ __device__ __forceinline__ void traverse(const DevScene &S, int *stk, f3 o, f3 d
                                          uint32_t &c_nodes, uint32_t &c_prims)
 {
     const float t_min = 0.001f;
+    if (S.nprim == 0u) return;
     // Box culling only has to be conservative (boxes are padded); it never
     // decides a hit, so it may use any arithmetic.
     const float tiny = 1.0e-20f;

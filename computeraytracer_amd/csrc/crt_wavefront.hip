@@ -95,41 +95,16 @@ __device__ __forceinline__ void wavelengths_of(uint32_t lambda, uint32_t wl[4])
     wl[3] = (lambda + 12u) % kNLambda;                           // :321
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_wf_shade(const WfParams P, uint32_t it)
+struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary; };
+struct ShadeCnt { uint32_t rays = 0, bounces = 0, shadow = 0, hits = 0, paths = 0, prims = 0, walk = 0; };
+
+// One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
+// driven by k_wf_finish (no re-arming from the work queue; the caller traces the emitted rays itself).
+template <bool COUNT, bool FINISH>
+__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, bool via_shadow_list,
+                                               uint32_t my_shard, ShadeCnt &cn)
 {
     const DevScene &S = P.sc;
-    const uint32_t ring = it & 3u, lbuf = it & 1u;
-    WfCtl *ctl = P.ctl;
-    if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
-        WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
-        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
-    }
-    uint32_t slot, my_shard;
-    bool in_pool, via_shadow_list = false;
-    if (P.tail_bound == 0u) {
-        const uint32_t local = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
-        slot = P.slot_base + local;
-        my_shard = blockIdx.x % kWfShards;
-        in_pool = local < P.P;
-    } else {
-        // Tail mode (no work left, few paths alive): every alive slot listed a ray last iteration,
-        // so walk those lists instead of the whole pool.  Per shard: threads [c*bound,(c+1)*bound)
-        // take list class c; shadow-class entries only count for slots that are dying, i.e. not
-        // also in an extension list.
-        const uint32_t bps = (4u * P.tail_bound + (uint32_t)CRT_WF_SHADE_BLOCK - 1u) / (uint32_t)CRT_WF_SHADE_BLOCK;
-        my_shard = blockIdx.x / bps;
-        const uint32_t j = (blockIdx.x % bps) * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
-        const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
-        const size_t region = (size_t)my_shard * P.list_cap;
-        slot = 0; in_pool = false;
-        const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
-        if (cls < 4u && e < pv.n[cls]) {
-            slot = P.list[lbuf ^ 1u][cls][region + e]; in_pool = true; via_shadow_list = cls >= 2u;
-        }
-    }
-    uint32_t c_rays = 0, c_bounces = 0, c_shadow = 0, c_hits = 0, c_paths = 0, c_prims = 0, c_walk = 0;
-
     PathRegs R;
     R.flags = 0;
     // Every per-slot stream is loaded up front in ONE batch (the kernel is bound by dependent
@@ -174,7 +149,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         } else {
             // 2. the extension ray's closest hit (:135-146)
             const uint32_t b_slot = h_slot;
-            if (COUNT) c_bounces++;
+            if (COUNT) cn.bounces++;
             if (b_slot == kNoHit) {
                 finished = true;                                 // :141
             } else {
@@ -189,7 +164,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                     const f3 n0 = ((meta & 3u) == 0u) ? xyz(hD) : normalize(cross(xyz(hB), xyz(hC)));
                     nrm = (dot(n0, d) > 0.0f) ? -n0 : n0;                    // :541-544
                 }
-                if (COUNT) c_hits++;
+                if (COUNT) cn.hits++;
                 const uint32_t b_index = f_bits(hB.w);
                 R.exclude = b_index;                             // :146
                 const uint32_t material = (meta >> 2) & 3u;
@@ -227,13 +202,13 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                         f3 pl = (xyz(L0) + xyz(L1) * u) + xyz(L2) * v2;
                         f3 ldir = normalize(pl - pos);
                         const uint32_t include = f_bits(L1.w);
-                        if (COUNT) { c_rays++; c_shadow++; }
+                        if (COUNT) { cn.rays++; cn.shadow++; }
                         // shadow_intersect (:697-705): the light's own primitive first
                         float t_l = CRT_INFINITY;
                         uint32_t l_index = kNoHit, l_slot = kNoHit;
                         if (include < S.nprim && finite3(ldir)) {
                             hit_test<false>(S, S.slot_of_index[include], pos, ldir, b_index, 0.001f, t_l, l_index, l_slot);
-                            if (COUNT) c_prims++;
+                            if (COUNT) cn.prims++;
                         }
                         // cos_theta == 0 (the light sample is behind the surface): le = spec*0 is exactly 0, so the
                         // NEE term (:400) is exactly +0 whatever the visibility -- adding it changes nothing, and
@@ -242,7 +217,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                         if (l_slot != kNoHit && cos_theta > 0.0f) {
                             f3 lp, ln; uint32_t lmeta;
                             hit_attributes(S, l_slot, pos, ldir, t_l, lp, ln, lmeta);
-                            if (COUNT) c_hits++;
+                            if (COUNT) cn.hits++;
                             f4 spec = sample_spectrum(S, f_bits(L0.w), wl);
                             f4 le = spec * cos_theta;
                             float pdf_l = compute_light_pdf(S, (lmeta >> 4) & 0x3FFFu, lp, ln, pos, ldir);
@@ -256,7 +231,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                             emit_sh = true;
                             sh_primary = depth == 0u;
                             R.flags |= kWfShadow;
-                            if (COUNT) c_walk++;
+                            if (COUNT) cn.walk++;
                         }
                         // non-finite light direction: the reference loop decides (never seen in practice;
                         // handled by tracing it as a brute-force ray in the mega kernel) -> treated as blocked
@@ -308,7 +283,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                         depth++;
                         R.flags = (R.flags & ~(0xFFu << kWfDepthShift)) | (depth << kWfDepthShift);
                         emit_ext = true;
-                        if (COUNT) { c_rays++; c_walk++; }
+                        if (COUNT) { cn.rays++; cn.walk++; }
                     }
                 }
             }
@@ -321,10 +296,11 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
             f3 c = spectral_to_xyz(S, R.radiance, wl);
             P.staging[(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
             alive = false;
-            if (COUNT) c_paths++;
+            if (COUNT) cn.paths++;
         }
     }
 
+    if (!FINISH) {
     // 3. re-arm dead slots with the next (sample, pixel) work item.  The work range is split
     //    into kWfShards contiguous sub-ranges with their own cursors; a wave looks at all cursors
     //    with one wave-wide load, picks a non-empty shard (its own first) and takes what it
@@ -396,7 +372,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                     emit_ext = true;
                     ext_primary = true;
                     emit_sh = false;
-                    if (COUNT) { c_rays++; c_walk++; }
+                    if (COUNT) { cn.rays++; cn.walk++; }
                 }
                 // (a work item outside a ragged tile is consumed without a path; the slot retries)
                 else want = true;
@@ -405,7 +381,9 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         if (want0 && !alive) R.flags = 0;
     }
 
-    // 4. write the slot back and compact the active rays (ballot/popc, one atomic per wave per list)
+    }
+
+    // 4. write the slot back
     if (in_pool) {
         if (alive) {
             P.ray_o[slot] = float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)};
@@ -416,7 +394,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
             if (emit_ext && (!finite3(R.ray_o) || !finite3(R.ray_d))) {
                 resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, R.ray_o.x, R.ray_o.y, R.ray_o.z,
                                   R.ray_d.x, R.ray_d.y, R.ray_d.z, R.exclude, &P.hit[slot]);
-                if (COUNT) c_prims += S.nprim;
+                if (COUNT) cn.prims += S.nprim;
                 resolved = 1u;
             }
             P.ray_d[slot] = float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)};
@@ -426,6 +404,45 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         }
         P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
     }
+    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary};
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_wf_shade(const WfParams P, uint32_t it)
+{
+    const DevScene &S = P.sc;
+    const uint32_t ring = it & 3u, lbuf = it & 1u;
+    WfCtl *ctl = P.ctl;
+    if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
+        WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
+        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
+    }
+    uint32_t slot, my_shard;
+    bool in_pool, via_shadow_list = false;
+    if (P.tail_bound == 0u) {
+        const uint32_t local = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
+        slot = P.slot_base + local;
+        my_shard = blockIdx.x % kWfShards;
+        in_pool = local < P.P;
+    } else {
+        // Tail mode (no work left, few paths alive): every alive slot listed a ray last iteration,
+        // so walk those lists instead of the whole pool.  Per shard: threads [c*bound,(c+1)*bound)
+        // take list class c; shadow-class entries only count for slots that are dying, i.e. not
+        // also in an extension list.
+        const uint32_t bps = (4u * P.tail_bound + (uint32_t)CRT_WF_SHADE_BLOCK - 1u) / (uint32_t)CRT_WF_SHADE_BLOCK;
+        my_shard = blockIdx.x / bps;
+        const uint32_t j = (blockIdx.x % bps) * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
+        const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
+        const size_t region = (size_t)my_shard * P.list_cap;
+        slot = 0; in_pool = false;
+        const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
+        if (cls < 4u && e < pv.n[cls]) {
+            slot = P.list[lbuf ^ 1u][cls][region + e]; in_pool = true; via_shadow_list = cls >= 2u;
+        }
+    }
+    ShadeCnt cn;
+    const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, via_shadow_list, my_shard, cn);
+    const bool emit_ext = so.emit_ext, ext_primary = so.ext_primary, emit_sh = so.emit_sh, sh_primary = so.sh_primary;
     {
         const uint32_t lane = lane_id();
         // Four ray classes keep like with like in the traversal kernel: camera rays (coherent),
@@ -449,13 +466,13 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         if (cl3) P.list[lbuf][3][region + b3 + prefix_popc(m3, lane)] = slot;
     }
     if (COUNT) {
-        wave_add(ctl->counters + CRT_CNT_RAYS, c_rays);
-        wave_add(ctl->counters + CRT_CNT_BOUNCES, c_bounces);
-        wave_add(ctl->counters + CRT_CNT_SHADOW, c_shadow);
-        wave_add(ctl->counters + CRT_CNT_HITS, c_hits);
-        wave_add(ctl->counters + CRT_CNT_PATHS, c_paths);
-        wave_add(ctl->counters + CRT_CNT_PRIMS, c_prims);
-        wave_add(ctl->counters + CRT_CNT_WALKED, c_walk);
+        wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
+        wave_add(ctl->counters + CRT_CNT_BOUNCES, cn.bounces);
+        wave_add(ctl->counters + CRT_CNT_SHADOW, cn.shadow);
+        wave_add(ctl->counters + CRT_CNT_HITS, cn.hits);
+        wave_add(ctl->counters + CRT_CNT_PATHS, cn.paths);
+        wave_add(ctl->counters + CRT_CNT_PRIMS, cn.prims);
+        wave_add(ctl->counters + CRT_CNT_WALKED, cn.walk);
     }
 }
 
@@ -785,6 +802,77 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     }
 }
 
+// ------------------------------------------------------------------ finish
+// The last few paths of a batch (no work left, a few thousand slots alive at most): one lane
+// per remaining slot runs its path to the end -- trace the pending rays itself (plain BVH2 walk,
+// any-hit for the shadow ray), shade, repeat -- so the tail costs one ray latency per bounce
+// instead of two kernel launches per bounce.  Slots come from the previous iteration's ray lists
+// exactly as in k_wf_shade's tail mode.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, uint32_t it)
+{
+    __shared__ int lds_stack[kStackDepth * 64];
+    const DevScene &S = P.sc;
+    WfCtl *ctl = P.ctl;
+    int *stk = lds_stack + lane_id();
+    const uint32_t lbuf = it & 1u;
+    const uint32_t bps = (4u * P.tail_bound + 63u) / 64u;
+    const uint32_t my_shard = blockIdx.x / bps;
+    const uint32_t j = (blockIdx.x % bps) * 64u + threadIdx.x;
+    const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
+    const size_t region = (size_t)my_shard * P.list_cap;
+    uint32_t slot = 0;
+    bool mine = false, via_shadow_list = false;
+    const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
+    if (cls < 4u && e < pv.n[cls]) { slot = P.list[lbuf ^ 1u][cls][region + e]; mine = true; via_shadow_list = cls >= 2u; }
+    uint32_t flags = 0;
+    if (mine) flags = P.misc[slot].y;
+    if (via_shadow_list && !(flags & kWfDying)) mine = false;           // reached through its extension ray instead
+    bool alive = mine && (flags & kWfAlive);
+    // The rays these slots listed in iteration it-1 were already traced by k_wf_trace(it-1): start with
+    // the shade step; from then on this lane traces what its own shade steps emit.
+    bool pend_sh = false, pend_ext = false;
+    ShadeCnt cn;
+    uint32_t c_nodes = 0, c_prims = 0;
+    for (int guard = 0; guard < 512 && __ballot(alive) != 0ull; guard++) {
+        if (alive) {
+            const float4 ro = P.ray_o[slot];
+            const f3 o = xyz(ro);
+            const uint32_t excl = f_bits(ro.w);
+            if (pend_sh) {
+                const float4 sd = P.sh_d[slot];
+                float t_max = sd.w;
+                uint32_t b_index = P.vis[slot];                          // the light's primitive index
+                const uint32_t l_slot = S.slot_of_index[b_index];
+                uint32_t b_slot = l_slot;
+                traverse<COUNT>(S, stk, o, xyz(sd), excl, true, t_max, b_index, b_slot, c_nodes, c_prims);
+                P.vis[slot] = (b_slot == l_slot) ? 1u : 0u;
+            }
+            if (pend_ext) {
+                const float4 rd = P.ray_d[slot];
+                if (f_bits(rd.w) == 0u) {                                // (else: non-finite ray, resolved by the shade step)
+                    float t_max = CRT_INFINITY;
+                    uint32_t b_index = kNoHit, b_slot = kNoHit;
+                    traverse<COUNT>(S, stk, o, xyz(rd), excl, false, t_max, b_index, b_slot, c_nodes, c_prims);
+                    P.hit[slot] = float2{t_max, bits_f(b_slot)};
+                }
+            }
+            const ShadeOut so = shade_body<COUNT, true>(P, slot, true, false, my_shard, cn);
+            alive = so.alive; pend_ext = so.emit_ext; pend_sh = so.emit_sh;
+        }
+    }
+    if (COUNT) {
+        wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
+        wave_add(ctl->counters + CRT_CNT_BOUNCES, cn.bounces);
+        wave_add(ctl->counters + CRT_CNT_SHADOW, cn.shadow);
+        wave_add(ctl->counters + CRT_CNT_HITS, cn.hits);
+        wave_add(ctl->counters + CRT_CNT_PATHS, cn.paths);
+        wave_add(ctl->counters + CRT_CNT_PRIMS, cn.prims + c_prims);
+        wave_add(ctl->counters + CRT_CNT_WALKED, cn.walk);
+        wave_add(ctl->counters + CRT_CNT_NODES, c_nodes);
+    }
+}
+
 // ------------------------------------------------------------------ resolve
 __global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t last_sample)
 {
@@ -837,6 +925,15 @@ hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks
     const bool q = CRT_WF_BVH4 && P.sc.nodes4q != nullptr;
     if (P.count) { if (q) hipLaunchKernelGGL((k_wf_trace<true, true>), g, b, 0, s, P, it); else hipLaunchKernelGGL((k_wf_trace<true, false>), g, b, 0, s, P, it); }
     else { if (q) hipLaunchKernelGGL((k_wf_trace<false, true>), g, b, 0, s, P, it); else hipLaunchKernelGGL((k_wf_trace<false, false>), g, b, 0, s, P, it); }
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_finish(const WfParams &P, uint32_t it, hipStream_t s)
+{
+    if (P.tail_bound == 0u) return hipErrorInvalidValue;
+    const uint32_t bps = (4u * P.tail_bound + 63u) / 64u;
+    if (P.count) hipLaunchKernelGGL((k_wf_finish<true>), dim3(kWfShards * bps), dim3(64), 0, s, P, it);
+    else hipLaunchKernelGGL((k_wf_finish<false>), dim3(kWfShards * bps), dim3(64), 0, s, P, it);
     return hipGetLastError();
 }
 

@@ -314,6 +314,24 @@ def test_counters_match_oracle_and_walked_is_a_subset(renderer, orc):
     assert 0 < c["walked"] <= c["rays"] and c["rays"] - c["walked"] <= c["shadow"]
 
 
+def test_two_pipes_with_long_tails_repeatable(renderer, orc):
+    """Regression: cornell 1000x1000 has ~1000 paths trapped in the glass sphere until MAXDEPTH, i.e. a
+    100-iteration tail; with two concurrent half-pool pipes and the (slow) counting kernels this once gave a
+    few wrong pixels per frame.  Must be bit-exact every time, with and without the finish kernel."""
+    from computeraytracer_amd import cornell
+    ps = cornell()
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(2)
+    try:
+        for finish_at, count in [(0, True), (4096, True), (4096, False)]:
+            renderer.set_option("wf_finish_at", finish_at).set_option("wf_pipes", 2)
+            for _ in range(3):
+                renderer.upload(ps).build_accel("bvh2").enable_counters(count).reset_counters()
+                renderer.frame(2).sync()
+                assert_same_image(renderer.read_accum(), renderer.read_rgba8(), acc_o, rgba_o)
+    finally:
+        renderer.enable_counters(False).set_option("wf_finish_at", 4096)
+
+
 def test_one_sample_per_pixel_and_tiny_tiles(renderer, orc):
     """Pool larger than the work (1 spp on a small tile) and a 1x1 tile."""
     from computeraytracer_amd import cornell
