@@ -184,6 +184,8 @@ def main():
                          "node_bytes_per_box": st["bytes_per_box"], "node_width": st["width"],
                          "boxes_per_ray": round(m_nodes / max(m_rays, 1), 2), "prims_per_ray": round(m_prims / max(m_rays, 1), 2),
                          "kernel_share_of_pass": round(kernel_ms / max(total_ms, 1e-9), 3),
+                         "note": "two half-pool pipes run on two streams, so two k_wf_trace launches (and a k_wf_shade) overlap: "
+                                 "summed launch durations exceed the wall time of the pass; whole_pass_* = bytes / wall time",
                          "whole_pass_GBs": round(whole_pass, 1), "whole_pass_frac": round(whole_pass / HBM_PEAK_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
