@@ -159,6 +159,14 @@ def main():
         avg_ms = kernel_ms / max(launches, 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         whole_pass = alg_bytes / (total_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:    # HBM bytes per launch from the committed PMC passes of this exact workload (a bench run cannot profile itself)
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if tj["workload"] == f"{args.scene} {W}x{H} {args.spp}spp n_gpus={world}":
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Mrays/sec (+ HBM GB/s vs peak), 1080p 250k-tri scene, 1/2/4/8 MI355X",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,7 +185,7 @@ def main():
                              "(cos_theta == 0) or whose light primitive is missed are decided without a BVH walk"},
             "mrays_walked_per_s": round(walked / elapsed / 1e6, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_wf_trace", "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": round(per_launch),
                          "bytes_per_ray": round(alg_bytes / max(m_rays, 1), 1),
