@@ -547,10 +547,15 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             if (!work_left && rays < std::min<unsigned long long>((unsigned long long)Pp / 4u, 65536ull)) {
                 // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
                 // the ray lists instead of the whole pool and the grids shrink.
-                // From the first pipe that gets here on, every pipe continues on the context's stream:
-                // the tiny tail kernels of one pipe running concurrently with another pipe's kernels gave
-                // rare wrong pixels on MI355X (a few in 10^6, only with both conditions; root cause not
-                // pinned down, the overlap is worthless in the tail anyway).
+                // From the first pipe that gets here on, every pipe continues on the context's stream.
+                // Measured on MI355X: list-walking shade kernels of one pipe running CONCURRENTLY with the
+                // other pipe's kernels gave a few wrong pixels per 10^6 (stale per-slot state), never on
+                // one stream and never with the pool-order shade.  What differs: in pool order a slot is
+                // always shaded by the same block index, i.e. on the same XCD, and a full pass streams far
+                // more than an L2 holds; in tail mode the slot moves between XCDs and the footprint is tiny,
+                // so a stale clean L2 line can survive unless every kernel start invalidates it -- which
+                // evidently is not guaranteed while a second queue is active.  The overlap is worthless in
+                // the tail anyway.
                 if (!serial) {
                     serial = true;
                     for (int q = 1; q < K; q++) {
