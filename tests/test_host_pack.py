@@ -127,3 +127,17 @@ def test_image_writers(tmp_path):
     n = struct.unpack(">I", png[i - 4:i])[0]
     rows = np.frombuffer(zlib.decompress(png[i + 4:i + 4 + n]), np.uint8).reshape(5, 1 + 7 * 4)
     assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(5, 7, 4), rgba)
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_webgpu_facade_turns_submits_into_library_calls():
+    """host/webgpu.js: one upload + accel build for the five storage buffers,
+    then one trace(1) per submitted path-trace pass; the counter pass adds nothing."""
+    out = subprocess.run([shutil.which("node"), os.path.join(ROOT, "tests", "facade_stub.js")],
+                         capture_output=True, text=True, check=True)
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    from computeraytracer_amd import scene as S
+    ps = S.cornell(16, 16)
+    sizes = [getattr(ps, k).nbytes for k in ("primitives", "lights", "spectra", "cie", "camera")]
+    assert got["calls"] == [["upload"] + sizes, ["accel", 1], ["trace", 1], ["trace", 1], ["destroy"]]
+    assert got["px"] == 7 and got["n"] == 16 * 16 * 4

@@ -30,3 +30,18 @@ def test_node_host_matches_oracle(tmp_path, orc, unfused):
     assert info["rays"] == int(cnt[0])
     ppm = (tmp_path / "img.ppm").read_bytes()
     assert ppm.startswith(b"P6\n96 72\n255\n") and len(ppm) == 13 + 96 * 72 * 3
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_webgpu_shaped_host_matches_oracle(tmp_path, orc):
+    """host/webgpu_main.js speaks WebGPU only (buffers, bind groups, command encoders,
+    requestAnimationFrame); host/webgpu.js turns its submits into libcrt calls."""
+    from computeraytracer_amd import cornell
+    cmd = [NODE, os.path.join(ROOT, "host", "webgpu_main.js"), "--size", "80", "--frames", "3",
+           "--dump", str(tmp_path / "fb.bin"), "--out", str(tmp_path / "fb.ppm")]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info == {"width": 80, "height": 80, "frames": 3}
+    rgba = np.frombuffer((tmp_path / "fb.bin").read_bytes(), np.uint8).reshape(80, 80, 4)
+    _, rgba_o, _ = orc.Scene.from_packed(cornell(80, 80)).render(3)
+    assert np.array_equal(rgba, rgba_o)
