@@ -129,6 +129,7 @@ struct crt_ctx {
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
+    int wf_serial_tail = 0;         // 1: once a pipe reaches the tail, all pipes continue on one stream
     uint32_t wf_finish_at = 4096;   // rays left (per pipe) at which k_wf_finish takes over; 0 = never
     DevBuf<WfCtl> w_ctl[kMaxPipes];
     DevBuf<WfWorkQ> w_wq;
@@ -535,7 +536,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             // pipe 0's view of the queue can lag the others by a chunk; a pipe with no rays while work
             // may be left simply keeps going (its dead slots re-arm as soon as they see work)
             if (!work_left && rays == 0) { pp.done = true; active--; continue; }   // every alive slot lists a ray
-            if (!work_left && rays <= c->wf_finish_at && serial) {
+            if (!work_left && rays <= c->wf_finish_at && (serial || !c->wf_serial_tail)) {
                 // A few paths left: one kernel runs them to the end (ray counts only shrink from here, so
                 // `bound` also covers the chunk already enqueued ahead).
                 pp.W.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
@@ -547,16 +548,11 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             if (!work_left && rays < std::min<unsigned long long>((unsigned long long)Pp / 4u, 65536ull)) {
                 // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
                 // the ray lists instead of the whole pool and the grids shrink.
-                // From the first pipe that gets here on, every pipe continues on the context's stream.
-                // Measured on MI355X: list-walking shade kernels of one pipe running CONCURRENTLY with the
-                // other pipe's kernels gave a few wrong pixels per 10^6 (stale per-slot state), never on
-                // one stream and never with the pool-order shade.  What differs: in pool order a slot is
-                // always shaded by the same block index, i.e. on the same XCD, and a full pass streams far
-                // more than an L2 holds; in tail mode the slot moves between XCDs and the footprint is tiny,
-                // so a stale clean L2 line can survive unless every kernel start invalidates it -- which
-                // evidently is not guaranteed while a second queue is active.  The overlap is worthless in
-                // the tail anyway.
-                if (!serial) {
+                // wf_serial_tail = 1 joins every pipe onto the context's stream from here on (a debugging
+                // aid: it is how the double visit of a slot by the list-walking shade was told apart from
+                // a coherence problem); by default the pipes stay concurrent, which is
+                // worth ~1 ms per batch.
+                if (!serial && c->wf_serial_tail) {
                     serial = true;
                     for (int q = 1; q < K; q++) {
                         if (pipes[q].stream == c->stream) continue;
@@ -1010,6 +1006,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
     if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
     if (!std::strcmp(name, "wf_finish_at")) { c->wf_finish_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
+    if (!std::strcmp(name, "wf_serial_tail")) { c->wf_serial_tail = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }

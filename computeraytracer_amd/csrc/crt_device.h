@@ -76,6 +76,8 @@ struct TraceParams {
 //   list[parity][class]                   slots with an active ray this iteration (ballot/popc compacted)
 //   staging (xyz, -) per (sample, pixel)  finished samples, summed in sample order by k_wf_resolve
 constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
+// ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
+constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;
 constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
 
 // Every queue counter is sharded kWfShards ways, one 128-byte line per shard: same-address

@@ -101,8 +101,7 @@ struct ShadeCnt { uint32_t rays = 0, bounces = 0, shadow = 0, hits = 0, paths = 
 // One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
 // driven by k_wf_finish (no re-arming from the work queue; the caller traces the emitted rays itself).
 template <bool COUNT, bool FINISH>
-__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, bool via_shadow_list,
-                                               uint32_t my_shard, ShadeCnt &cn)
+__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, uint32_t my_shard, ShadeCnt &cn)
 {
     const DevScene &S = P.sc;
     PathRegs R;
@@ -118,7 +117,6 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         v_rad = P.radiance[slot]; rs = P.rng[slot]; h = P.hit[slot]; vis_in = P.vis[slot]; v_nee = P.nee[slot];
     }
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
-    if (via_shadow_list && !(R.flags & kWfDying)) in_pool = false;   // reached through its extension ray instead
     bool alive = in_pool && (R.flags & kWfAlive);
     bool emit_ext = false, emit_sh = false;
     bool ext_primary = false, sh_primary = false;     // ray classes: camera ray / shadow ray of a camera-ray hit
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
     }
     uint32_t slot, my_shard;
-    bool in_pool, via_shadow_list = false;
+    bool in_pool;
     if (P.tail_bound == 0u) {
         const uint32_t local = blockIdx.x * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
         slot = P.slot_base + local;
@@ -427,8 +425,10 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     } else {
         // Tail mode (no work left, few paths alive): every alive slot listed a ray last iteration,
         // so walk those lists instead of the whole pool.  Per shard: threads [c*bound,(c+1)*bound)
-        // take list class c; shadow-class entries only count for slots that are dying, i.e. not
-        // also in an extension list.
+        // take list class c; a shadow-list entry whose slot also listed an extension ray carries
+        // kWfListAlsoExt and is skipped here.  (The mark is made when the entry is written: the slot's
+        // flags cannot be consulted, the thread that holds the slot's extension entry rewrites them in
+        // this very launch.)
         const uint32_t bps = (4u * P.tail_bound + (uint32_t)CRT_WF_SHADE_BLOCK - 1u) / (uint32_t)CRT_WF_SHADE_BLOCK;
         my_shard = blockIdx.x / bps;
         const uint32_t j = (blockIdx.x % bps) * (uint32_t)CRT_WF_SHADE_BLOCK + threadIdx.x;
@@ -437,11 +437,13 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         slot = 0; in_pool = false;
         const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
         if (cls < 4u && e < pv.n[cls]) {
-            slot = P.list[lbuf ^ 1u][cls][region + e]; in_pool = true; via_shadow_list = cls >= 2u;
+            const uint32_t entry = P.list[lbuf ^ 1u][cls][region + e];
+            slot = entry & kWfListSlot;
+            in_pool = !(entry & kWfListAlsoExt);                 // else reached through its extension ray
         }
     }
     ShadeCnt cn;
-    const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, via_shadow_list, my_shard, cn);
+    const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, my_shard, cn);
     const bool emit_ext = so.emit_ext, ext_primary = so.ext_primary, emit_sh = so.emit_sh, sh_primary = so.sh_primary;
     {
         const uint32_t lane = lane_id();
@@ -462,8 +464,9 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         const size_t region = (size_t)my_shard * P.list_cap;
         if (cl0) P.list[lbuf][0][region + b0 + prefix_popc(m0, lane)] = slot;
         if (cl1) P.list[lbuf][1][region + b1 + prefix_popc(m1, lane)] = slot;
-        if (cl2) P.list[lbuf][2][region + b2 + prefix_popc(m2, lane)] = slot;
-        if (cl3) P.list[lbuf][3][region + b3 + prefix_popc(m3, lane)] = slot;
+        const uint32_t sh_entry = slot | (emit_ext ? kWfListAlsoExt : 0u);
+        if (cl2) P.list[lbuf][2][region + b2 + prefix_popc(m2, lane)] = sh_entry;
+        if (cl3) P.list[lbuf][3][region + b3 + prefix_popc(m3, lane)] = sh_entry;
     }
     if (COUNT) {
         wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
@@ -603,8 +606,8 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     const uint32_t idx = chunk_pos + my;
                     const size_t region = (size_t)cur_shard * P.list_cap;
                     shadow = idx >= sh_e1;
-                    slot = idx < sh_e0 ? list0[region + idx] : idx < sh_e1 ? list1[region + (idx - sh_e0)]
-                         : idx < sh_e2 ? list2[region + (idx - sh_e1)] : list3[region + (idx - sh_e2)];
+                    slot = (idx < sh_e0 ? list0[region + idx] : idx < sh_e1 ? list1[region + (idx - sh_e0)]
+                          : idx < sh_e2 ? list2[region + (idx - sh_e1)] : list3[region + (idx - sh_e2)]) & kWfListSlot;
                     // set up the ray
                     const float4 ro = g_ray_o[slot];
                     o = xyz(ro); excl = f_bits(ro.w);
@@ -822,12 +825,15 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, uint32_t it)
     const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
     const size_t region = (size_t)my_shard * P.list_cap;
     uint32_t slot = 0;
-    bool mine = false, via_shadow_list = false;
+    bool mine = false;
     const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
-    if (cls < 4u && e < pv.n[cls]) { slot = P.list[lbuf ^ 1u][cls][region + e]; mine = true; via_shadow_list = cls >= 2u; }
+    if (cls < 4u && e < pv.n[cls]) {
+        const uint32_t entry = P.list[lbuf ^ 1u][cls][region + e];
+        slot = entry & kWfListSlot;
+        mine = !(entry & kWfListAlsoExt);                               // else reached through its extension ray
+    }
     uint32_t flags = 0;
     if (mine) flags = P.misc[slot].y;
-    if (via_shadow_list && !(flags & kWfDying)) mine = false;           // reached through its extension ray instead
     bool alive = mine && (flags & kWfAlive);
     // The rays these slots listed in iteration it-1 were already traced by k_wf_trace(it-1): start with
     // the shade step; from then on this lane traces what its own shade steps emit.
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, uint32_t it)
                     P.hit[slot] = float2{t_max, bits_f(b_slot)};
                 }
             }
-            const ShadeOut so = shade_body<COUNT, true>(P, slot, true, false, my_shard, cn);
+            const ShadeOut so = shade_body<COUNT, true>(P, slot, true, my_shard, cn);
             alive = so.alive; pend_ext = so.emit_ext; pend_sh = so.emit_sh;
         }
     }

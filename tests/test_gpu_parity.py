@@ -316,20 +316,23 @@ def test_counters_match_oracle_and_walked_is_a_subset(renderer, orc):
 
 def test_two_pipes_with_long_tails_repeatable(renderer, orc):
     """Regression: cornell 1000x1000 has ~1000 paths trapped in the glass sphere until MAXDEPTH, i.e. a
-    100-iteration tail; with two concurrent half-pool pipes and the (slow) counting kernels this once gave a
-    few wrong pixels per frame.  Must be bit-exact every time, with and without the finish kernel."""
+    100-iteration tail.  In the tail the shade kernel walks the ray lists, where a slot with an extension
+    ray AND a shadow ray appears twice; the thread holding the shadow entry once looked at the slot's flags
+    to find out -- flags that the thread holding the extension entry rewrites in the same launch.  With two
+    pipes on two streams (block start times spread out) that gave tens of wrong pixels per frame.  Must be
+    bit-exact every time: streams joined in the tail or not, with and without the finish kernel."""
     from computeraytracer_amd import cornell
     ps = cornell()
     acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(2)
     try:
-        for finish_at, count in [(0, True), (4096, True), (4096, False)]:
-            renderer.set_option("wf_finish_at", finish_at).set_option("wf_pipes", 2)
+        for serial_tail, finish_at, count in [(0, 0, True), (0, 4096, True), (0, 4096, False), (1, 4096, False), (1, 0, True)]:
+            renderer.set_option("wf_finish_at", finish_at).set_option("wf_pipes", 2).set_option("wf_serial_tail", serial_tail)
             for _ in range(3):
                 renderer.upload(ps).build_accel("bvh2").enable_counters(count).reset_counters()
                 renderer.frame(2).sync()
                 assert_same_image(renderer.read_accum(), renderer.read_rgba8(), acc_o, rgba_o)
     finally:
-        renderer.enable_counters(False).set_option("wf_finish_at", 4096)
+        renderer.enable_counters(False).set_option("wf_finish_at", 4096).set_option("wf_serial_tail", 0)
 
 
 def test_one_sample_per_pixel_and_tiny_tiles(renderer, orc):
