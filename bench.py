@@ -75,8 +75,10 @@ def main():
     ntri = int((ps.primitives["category"] == 2).sum())
 
     r = Renderer(local_rank)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
-    r.set_option("time_kernels", 1)     # HIP events around every launch of the traversal kernel
+    # one stream for the renderer and the collective (the null stream's handle, 0, would mean "the context's own")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
     r.upload(ps)
     sf = StripFrame(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
     sf.apply(r)
@@ -86,12 +88,23 @@ def main():
     # strips live in torch tensors (padded to equal size) so RCCL can gather them
     r.bind_output(sf.accum.data_ptr(), sf.rgba.data_ptr())
 
-    def step():
-        r.frame(args.spp)
-        sf.gather(accum=False)   # the path's one exchange step: all_gather of the rgba8 strips (RCCL over xGMI);
-                                 # the accumulator stays on its GPU like the reference's (gathered once at the end)
+    # A step = one frame() of args.spp samples + the path's one exchange step, the all_gather of the rgba8
+    # strips (RCCL over xGMI; the accumulator stays on its GPU like the reference's and is gathered once at
+    # the end).  Steps are software-pipelined the way a display loop is: crt_trace returns with the frame's
+    # last, longest paths still in flight (they finish under the next frame), so the gather issued after
+    # frame k ships frame k-1 -- complete, in stream order -- and frame K-1 is shipped after the final sync.
+    # K frames traced, K complete frames gathered, all inside the timed region.
+    def run_steps(k):
+        for i in range(k):
+            r.frame(args.spp)
+            if i > 0:
+                sf.gather(accum=False)
+        r.sync()
+        if k > 0:
+            sf.gather(accum=False)
 
     def barrier():
+        r.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -100,19 +113,16 @@ def main():
     full_check = os.environ.get("CRT_BENCH_CHECK") == "1"    # rehearsal: compare the gathered frame with a 1-GPU render
 
     r.reset()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel_ms, launches, total_ms = 0.0, 0, 0.0
+    run_steps(args.warmup)
+    r.set_option("time_kernels", 1)     # from here on: HIP events around every launch of the traversal kernel,
+    barrier()                           # on the stream it is launched on
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        ms, nl = r.last_kernel_ms()        # HIP events on the launch stream around the k_wf_trace launches
-        kernel_ms += ms                    # (waits for this step's kernels)
-        launches += nl
-        total_ms += r.last_trace_ms()[0]
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms, launches = r.last_kernel_ms()   # summed over every k_wf_trace launch of the timed region
+    r.set_option("time_kernels", 0)
+    total_ms = elapsed * 1e3
     sf.gather(accum=True)      # final readout of the f32 XYZ accumulator (outside the timed steps)
     if full_check and world > 1 and rank == 0:
         acc_all, rgba_all = sf.image()

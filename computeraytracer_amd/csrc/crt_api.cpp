@@ -59,6 +59,9 @@ HostPrim read_prim(const uint8_t *base, size_t i)
     return p;
 }
 
+struct WfRun;
+int wf_flush(struct ::crt_ctx *c);
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -122,13 +125,15 @@ struct crt_ctx {
     uint32_t wf_pool = 0;           // 0 = auto
     uint32_t wf_waves_per_cu = 14;  // per pipe
     int num_cu = 0;
-    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging;
+    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[2];
     DevBuf<uint4> w_rng, w_misc;
     DevBuf<float2> w_hit;
     DevBuf<uint32_t> w_vis, w_list_ext, w_list_sh;
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
+    int wf_defer = 1;               // 1: a batch ends parked, its last paths finish under the next batch (or at crt_sync)
+    WfRun *run = nullptr;           // pipeline state between calls
     int wf_serial_tail = 0;         // 1: once a pipe reaches the tail, all pipes continue on one stream
     uint32_t wf_finish_at = 4096;   // rays left (per pipe) at which k_wf_finish takes over; 0 = never
     DevBuf<WfCtl> w_ctl[kMaxPipes];
@@ -373,7 +378,8 @@ int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
         HIPCHK(c, c->w_rng.alloc(P)); HIPCHK(c, c->w_misc.alloc(P)); HIPCHK(c, c->w_hit.alloc(P));
         HIPCHK(c, c->w_vis.alloc(P));
     }
-    if (c->w_staging.n < staging_elems) HIPCHK(c, c->w_staging.alloc(staging_elems));
+    for (int b = 0; b < 2; b++)
+        if (c->w_staging[b].n < staging_elems) HIPCHK(c, c->w_staging[b].alloc(staging_elems));
     if (!c->w_wq.p) {
         HIPCHK(c, c->w_wq.alloc(1));
         HIPCHK(c, hipMemset(c->w_wq.p, 0, sizeof(WfWorkQ)));
@@ -407,22 +413,50 @@ struct WfPipe {
     WfParams W{};
     hipStream_t stream = nullptr;
     uint32_t it = 0, chunk = 4, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
-    int cur = 0;
-    bool done = false;
+    uint32_t it_fresh = 0;          // iterations >= it_fresh belong to the batch whose work queue is loaded
+    int cur = 0;                    // status buffer of the chunk that is outstanding between driver passes
+    bool done = false;              // no more chunks are enqueued for this pipe (drained, finished or parked)
+    bool old_clear = true;          // no path of the previous batch is alive in this pipe any more
+    unsigned long long rays = 0;    // rays listed by the last iteration whose status was read
 };
 
-// One batch of n samples through the wavefront pipeline (asynchronous except for the small
-// control-block readbacks that decide when the pool has drained).
-int wf_trace_batch(crt_ctx *c, uint32_t n)
+// A batch of samples whose paths are (or may still be) in the pool; `open` until k_wf_resolve has been
+// enqueued for it.
+struct WfBatch { bool open = false; uint32_t n = 0, last_sample = 0, parity = 0; };
+
+// The pipeline's state between driver calls.  A batch normally ENDS PARKED: its work queue is empty
+// but its last, long paths are still in the pool, one chunk of iterations is still enqueued, and the
+// next batch's work flows into the slots as they free up -- the path-length tail of one batch is
+// hidden under the bulk of the next instead of running on a nearly empty GPU.  wf_flush() runs the
+// stragglers to the end (tail mode, k_wf_finish) and resolves; every call that reads or changes state
+// flushes first.
+struct WfRun {
+    bool live = false;              // pipes are forked; every pipe has one outstanding chunk in status buffer [cur]
+    int K = 0;
+    uint32_t P = 0, Pp = 0, list_cap = 0, trace_blocks = 0, work_per_shard = 0;
+    unsigned long long work_total = 0;
+    WfPipe pipes[crt_ctx::kMaxPipes];
+    WfBatch cur, prev;
+    bool work_left = false, serial = false;
+};
+
+struct WfConfig {
+    uint32_t tiles_x, tiles_y, npix_padded, P, Pp, list_cap, work_per_shard;
+    int K;
+    unsigned long long work_total;
+    size_t npix, list_per_pipe;
+};
+
+WfConfig wf_config(crt_ctx *c, uint32_t n)
 {
-    const uint32_t tiles_x = (c->tw + 7) / 8, tiles_y = (c->th + 7) / 8;
-    const uint32_t npix_padded = tiles_x * tiles_y * 64u;
-    const size_t npix = (size_t)c->tw * c->th;
-    if (npix == 0 || n == 0) { c->sample += n; return CRT_OK; }
-    const unsigned long long work_total = (unsigned long long)n * npix_padded;
+    WfConfig g{};
+    g.tiles_x = (c->tw + 7) / 8; g.tiles_y = (c->th + 7) / 8;
+    g.npix_padded = g.tiles_x * g.tiles_y * 64u;
+    g.npix = (size_t)c->tw * c->th;
+    g.work_total = (unsigned long long)n * g.npix_padded;
     // pool: about 1/8 of the batch's paths in flight, between 1 M and 4 M slots (measured best on S2)
-    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 22, std::max<unsigned long long>(1u << 20, work_total / 8u));
-    if ((unsigned long long)P > work_total) P = (uint32_t)work_total;
+    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 22, std::max<unsigned long long>(1u << 20, g.work_total / 8u));
+    if ((unsigned long long)P > g.work_total) P = (uint32_t)g.work_total;
     // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
     // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
     int K = std::max(1, std::min(c->wf_pipes, (int)crt_ctx::kMaxPipes));
@@ -431,98 +465,88 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     // (measured: a 1/8 strip takes 13.0 ms with such a pool and 15.1 ms with one 0.4 % smaller)
     uint32_t Pp = P / (uint32_t)K;
     Pp = Pp >= 16384u ? (Pp / 16384u) * 16384u : ((Pp + 255u) & ~255u);
-    P = Pp * (uint32_t)K;
+    g.K = K; g.Pp = Pp; g.P = Pp * (uint32_t)K;
     // list capacity per shard: any shade block size >= 64 maps at most ceil(blocks/shards) blocks to a shard
-    const uint32_t list_cap = ((Pp / 64u + kWfShards - 1) / kWfShards) * 64u + 256u;
-    uint32_t work_per_shard = (uint32_t)((work_total + kWfShards - 1) / kWfShards);
-    work_per_shard = (work_per_shard + 63u) & ~63u;
-    const size_t list_per_pipe = (size_t)8 * list_cap * kWfShards;                 // [2 parities][4 classes]
-    int rc = wf_ensure(c, P, (size_t)n * npix, list_per_pipe * (size_t)K);
-    if (rc) return rc;
-    const uint32_t trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
+    g.list_cap = ((Pp / 64u + kWfShards - 1) / kWfShards) * 64u + 256u;
+    g.work_per_shard = (uint32_t)((g.work_total + kWfShards - 1) / kWfShards);
+    g.work_per_shard = (g.work_per_shard + 63u) & ~63u;
+    g.list_per_pipe = (size_t)8 * g.list_cap * kWfShards;                 // [2 parities][4 classes]
+    return g;
+}
 
-    WfPipe pipes[crt_ctx::kMaxPipes];
-    for (int p = 0; p < K; p++) {
-        WfParams &W = pipes[p].W;
-        W.sc = c->sc;
-        W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
-        W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
-        W.hit = c->w_hit.p; W.vis = c->w_vis.p;
-        for (int b = 0; b < 2; b++)
-            for (int k = 0; k < 4; k++)
-                W.list[b][k] = c->w_list_ext.p + list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * list_cap * kWfShards;
-        W.staging = c->w_staging.p; W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
-        W.slot_base = Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
-        W.P = Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
-        W.band = c->band; W.stride = c->stride; W.phase = c->phase;
-        W.tiles_x = tiles_x; W.tiles_y = tiles_y; W.npix_padded = npix_padded; W.work_total = work_total;
-        W.work_per_shard = work_per_shard; W.list_cap = list_cap;
-        W.first_sample = c->sample + 1; W.n_samples = n;
-        W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
-        W.count = c->counting ? 1u : 0u;
-        W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
-        W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * 64u;
-        pipes[p].stream = (p == 0) ? c->stream : c->pipe_stream[p];
-        pipes[p].blocks_now = trace_blocks;
-    }
-    // fork: pipe 0's init resets the shared work queue; the other streams start after it
-    HIPCHK(c, wf_launch_init(pipes[0].W, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    for (int p = 1; p < K; p++) {
-        HIPCHK(c, hipStreamWaitEvent(pipes[p].stream, c->ev_fork, 0));
-        HIPCHK(c, wf_launch_init(pipes[p].W, pipes[p].stream));
-    }
+int wf_resolve_batch(crt_ctx *c, WfBatch &b)
+{
+    WfRun &r = *c->run;
+    if (!b.open) return CRT_OK;
+    WfParams R = r.pipes[0].W;
+    R.batch_parity = b.parity; R.n_samples = b.n;
+    HIPCHK(c, wf_launch_resolve(R, b.last_sample, c->stream));
+    c->last_launches++;
+    b.open = false;
+    return CRT_OK;
+}
 
-    // Iterations are enqueued in chunks; after each chunk the small control blocks are copied back
-    // (asynchronously) so the host can tell when the pool has drained.  One chunk is always
-    // enqueued AHEAD of the status being waited for, so the GPU never idles on the host; the
-    // price is at most one chunk of empty iterations at the end.
-    auto enqueue_chunk = [&](int p, int buf) -> int {
-        WfPipe &pp = pipes[p];
-        pp.W.tail_bound = pp.tail_bound;
-        for (uint32_t k = 0; k < pp.chunk; k++, pp.it++) {
-            HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
-            if (c->time_kernels) {
-                size_t need = 2 * (size_t)(c->last_trace_kernel_launches + 1);
-                while (c->kev.size() < need) {
-                    hipEvent_t e;
-                    HIPCHK(c, hipEventCreate(&e));
-                    c->kev.push_back(e);
-                }
-                HIPCHK(c, hipEventRecord(c->kev[need - 2], pp.stream));
+// Iterations are enqueued in chunks; after each chunk the small control blocks are copied back
+// (asynchronously) so the host can tell how far the pool has drained.  One chunk is always
+// enqueued AHEAD of the status being waited for, so the GPU never idles on the host; the
+// price is at most one chunk of empty iterations at the end.
+int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
+{
+    WfPipe &pp = c->run->pipes[p];
+    pp.W.tail_bound = pp.tail_bound;
+    for (uint32_t k = 0; k < pp.chunk; k++, pp.it++) {
+        HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
+        if (c->time_kernels) {
+            size_t need = 2 * (size_t)(c->last_trace_kernel_launches + 1);
+            while (c->kev.size() < need) {
+                hipEvent_t e;
+                HIPCHK(c, hipEventCreate(&e));
+                c->kev.push_back(e);
             }
-            HIPCHK(c, wf_launch_trace(pp.W, pp.it, pp.blocks_now, pp.stream));
-            if (c->time_kernels) HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], pp.stream));
-            c->last_trace_kernel_launches++;
-            c->last_launches += 2;
+            HIPCHK(c, hipEventRecord(c->kev[need - 2], pp.stream));
         }
-        pp.it_end[buf] = pp.it;
-        HIPCHK(c, hipMemcpyAsync(c->h_ctl[p][buf], pp.W.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, pp.stream));
-        if (p == 0) HIPCHK(c, hipMemcpyAsync(c->h_wq[buf], c->w_wq.p, sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
-        HIPCHK(c, hipEventRecord(c->ev_ctl[p][buf], pp.stream));
-        return CRT_OK;
-    };
-    for (int p = 0; p < K; p++) { rc = enqueue_chunk(p, 0); if (rc) return rc; }
-    int active = K;
-    bool work_left = true, serial = false;
+        HIPCHK(c, wf_launch_trace(pp.W, pp.it, pp.blocks_now, pp.stream));
+        if (c->time_kernels) {
+            HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], pp.stream));
+            c->last_trace_kernel_launches++;
+        }
+        c->last_launches += 2;
+        c->last_iterations++;
+    }
+    pp.it_end[buf] = pp.it;
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl[p][buf], pp.W.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, pp.stream));
+    if (p == 0) HIPCHK(c, hipMemcpyAsync(c->h_wq[buf], c->w_wq.p, sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
+    HIPCHK(c, hipEventRecord(c->ev_ctl[p][buf], pp.stream));
+    return CRT_OK;
+}
+
+// Enqueue iterations and read statuses until the loaded batch is parked (to_end = false: its queue is
+// empty and the previous batch is resolved) or finished and resolved (to_end = true).
+int wf_drive(crt_ctx *c, bool to_end)
+{
+    WfRun &r = *c->run;
+    const int K = r.K;
+    int active = 0;
+    for (int p = 0; p < K; p++) { r.pipes[p].done = false; active++; }
     while (active > 0) {
         for (int p = 0; p < K; p++)
-            if (!pipes[p].done) { rc = enqueue_chunk(p, pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
+            if (!r.pipes[p].done) { int rc = wf_enqueue_chunk(c, p, r.pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
         for (int p = 0; p < K; p++) {
-            WfPipe &pp = pipes[p];
+            WfPipe &pp = r.pipes[p];
             if (pp.done) continue;
             HIPCHK(c, hipEventSynchronize(c->ev_ctl[p][pp.cur]));
+            if (pp.it_end[pp.cur] <= pp.it_fresh) { pp.cur ^= 1; continue; }      // a status from before this batch began
             if (p == 0) {
                 bool left = false;
                 for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-                    const unsigned long long lo = (unsigned long long)sidx * work_per_shard;
-                    const unsigned long long size = lo < work_total ? std::min<unsigned long long>(work_per_shard, work_total - lo) : 0;
+                    const unsigned long long lo = (unsigned long long)sidx * r.work_per_shard;
+                    const unsigned long long size = lo < r.work_total ? std::min<unsigned long long>(r.work_per_shard, r.work_total - lo) : 0;
                     if (c->h_wq[pp.cur]->work[sidx].cur < size) left = true;
                 }
-                work_left = left;                                // monotone: once false it stays false
+                r.work_left = left;                              // monotone within a batch: once false it stays false
             }
             const WfCtl *hc = c->h_ctl[p][pp.cur];
-            unsigned long long rays = 0;
+            unsigned long long rays = 0, old = 0;
             uint32_t bound = 0;
             for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
                 const WfShard &sh = hc->shard[(pp.it_end[pp.cur] - 1) & 3u][sidx];
@@ -531,68 +555,187 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
                 uint32_t alive_here = 0;
                 for (int k = 0; k < 4; k++) { rays += sh.n[k]; alive_here += sh.n[k]; }
                 bound = std::max(bound, alive_here);
+                old += sh.old;
             }
-            if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu work_left %d bound %u\n", p, pp.it_end[pp.cur], rays, (int)work_left, bound);
+            pp.rays = rays;
+            if (old == 0) pp.old_clear = true;                   // (paths of the previous batch cannot start any more)
+            if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu old %llu work_left %d bound %u\n", p, pp.it_end[pp.cur], rays, old, (int)r.work_left, bound);
             // pipe 0's view of the queue can lag the others by a chunk; a pipe with no rays while work
             // may be left simply keeps going (its dead slots re-arm as soon as they see work)
-            if (!work_left && rays == 0) { pp.done = true; active--; continue; }   // every alive slot lists a ray
-            if (!work_left && rays <= c->wf_finish_at && (serial || !c->wf_serial_tail)) {
-                // A few paths left: one kernel runs them to the end (ray counts only shrink from here, so
-                // `bound` also covers the chunk already enqueued ahead).
-                pp.W.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
-                HIPCHK(c, wf_launch_finish(pp.W, pp.it, pp.stream));
-                c->last_launches++;
-                pp.done = true; active--;
-                continue;
-            }
-            if (!work_left && rays < std::min<unsigned long long>((unsigned long long)Pp / 4u, 65536ull)) {
-                // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
-                // the ray lists instead of the whole pool and the grids shrink.
-                // wf_serial_tail = 1 joins every pipe onto the context's stream from here on (a debugging
-                // aid: it is how the double visit of a slot by the list-walking shade was told apart from
-                // a coherence problem); by default the pipes stay concurrent, which is
-                // worth ~1 ms per batch.
-                if (!serial && c->wf_serial_tail) {
-                    serial = true;
-                    for (int q = 1; q < K; q++) {
-                        if (pipes[q].stream == c->stream) continue;
-                        HIPCHK(c, hipEventRecord(c->ev_join[q], pipes[q].stream));
-                        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[q], 0));
-                        pipes[q].stream = c->stream;
-                    }
+            if (!r.work_left && rays == 0) { pp.done = true; pp.old_clear = true; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
+            if (!to_end) {
+                // Park: the queue is empty and the batch before this one is resolved.  The chunk already
+                // enqueued ahead keeps the GPU busy until the next batch's work arrives.
+                if (!r.work_left && !r.prev.open) { pp.done = true; pp.cur ^= 1; active--; continue; }
+            } else {
+                if (!r.work_left && rays <= c->wf_finish_at && (r.serial || !c->wf_serial_tail)) {
+                    // A few paths left: one kernel runs them to the end (ray counts only shrink from here, so
+                    // `bound` also covers the chunk already enqueued ahead).
+                    pp.W.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
+                    HIPCHK(c, wf_launch_finish(pp.W, pp.it, pp.stream));
+                    c->last_launches++;
+                    pp.rays = 0;
+                    pp.done = true; pp.old_clear = true; pp.cur ^= 1; active--;
+                    continue;
                 }
-                pp.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
-                pp.blocks_now = (uint32_t)std::min<unsigned long long>(trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
+                if (!r.work_left && rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull)) {
+                    // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
+                    // the ray lists instead of the whole pool and the grids shrink.
+                    // wf_serial_tail = 1 joins every pipe onto the context's stream from here on (a debugging
+                    // aid: it is how the double visit of a slot by the list-walking shade was told apart from
+                    // a coherence problem); by default the pipes stay concurrent, which is
+                    // worth ~1 ms per batch.
+                    if (!r.serial && c->wf_serial_tail) {
+                        r.serial = true;
+                        for (int q = 1; q < K; q++) {
+                            if (r.pipes[q].stream == c->stream) continue;
+                            HIPCHK(c, hipEventRecord(c->ev_join[q], r.pipes[q].stream));
+                            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[q], 0));
+                            r.pipes[q].stream = c->stream;
+                        }
+                    }
+                    pp.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
+                    pp.blocks_now = (uint32_t)std::min<unsigned long long>(r.trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
+                }
             }
-            if (pp.it > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+            if (pp.it - pp.it_fresh > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
             pp.cur ^= 1;
         }
-    }
-    // join: the resolve pass on the context's stream waits for every pipe
-    for (int p = 1; p < K; p++) {
-        if (pipes[p].stream == c->stream) continue;
-        HIPCHK(c, hipEventRecord(c->ev_join[p], pipes[p].stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
-    }
-    for (int p = 0; p < K; p++) c->last_iterations += pipes[p].it;
-    if (c->counting) {
-        // fold the pipes' counters into the context's
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        unsigned long long tot[CRT_NCOUNTERS];
-        HIPCHK(c, hipMemcpy(tot, c->d_counters.p, sizeof tot, hipMemcpyDeviceToHost));
-        for (int p = 0; p < K; p++) {
-            HIPCHK(c, hipMemcpy(c->h_ctl[p][0], c->w_ctl[p].p, sizeof(WfCtl), hipMemcpyDeviceToHost));
-            for (int k = 0; k < CRT_NCOUNTERS; k++) tot[k] += c->h_ctl[p][0]->counters[k];
-            for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl[p][0]->counters[8 + k];
-            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
+        // the previous batch's last paths are through (every pipe said so, or is empty): its frame can be resolved
+        if (r.prev.open) {
+            bool clear = true;
+            for (int p = 0; p < K; p++) clear = clear && r.pipes[p].old_clear;
+            if (clear) { int rc = wf_resolve_batch(c, r.prev); if (rc) return rc; }
         }
-        HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
+    }
+    bool empty = true;
+    for (int p = 0; p < K; p++) empty = empty && r.pipes[p].rays == 0;
+    if (to_end || empty) {
+        // everything enqueued for the other pipes comes before the resolve pass on the context's stream
+        for (int p = 1; p < K; p++) {
+            if (r.pipes[p].stream == c->stream) continue;
+            HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+        }
+        int rc = wf_resolve_batch(c, r.prev);
+        if (rc) return rc;
+        if (c->counting) {
+            // fold the pipes' counters into the context's
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            unsigned long long tot[CRT_NCOUNTERS];
+            HIPCHK(c, hipMemcpy(tot, c->d_counters.p, sizeof tot, hipMemcpyDeviceToHost));
+            for (int p = 0; p < K; p++) {
+                HIPCHK(c, hipMemcpy(c->h_ctl[p][0], c->w_ctl[p].p, sizeof(WfCtl), hipMemcpyDeviceToHost));
+                for (int k = 0; k < CRT_NCOUNTERS; k++) tot[k] += c->h_ctl[p][0]->counters[k];
+                for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl[p][0]->counters[8 + k];
+                HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
+            }
+            HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
+        }
+        rc = wf_resolve_batch(c, r.cur);
+        if (rc) return rc;
+    }
+    if (to_end) r.live = false;      // the pool is empty; the next batch sets the pipes up afresh
+    return CRT_OK;
+}
+
+// Finish whatever the pipeline still holds (no-op when nothing is parked).
+int wf_flush(crt_ctx *c)
+{
+    if (!c->run || !c->run->live) return CRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = wf_drive(c, true);
+    if (rc == CRT_OK && c->last_timed) HIPCHK(c, hipEventRecord(c->ev1, c->stream));   // crt_last_trace_ms covers the stragglers too
+    return rc;
+}
+
+// One batch of n samples through the wavefront pipeline (asynchronous except for the small
+// control-block readbacks that tell how far the pool has drained).
+int wf_trace_batch(crt_ctx *c, uint32_t n)
+{
+    if (!c->run) c->run = new WfRun();
+    WfRun &r = *c->run;
+    const WfConfig g = wf_config(c, n);
+    if (g.npix == 0 || n == 0) { int rc = wf_flush(c); c->sample += n; return rc; }
+    // counting folds counters on the host after every batch; otherwise batches end parked
+    const bool defer = c->wf_defer && !c->counting;
+    const size_t staging_elems = (size_t)n * g.npix;
+    if (r.live && (g.K != r.K || g.Pp != r.Pp || c->w_staging[0].n < staging_elems || r.prev.open)) {
+        int rc = wf_flush(c);
+        if (rc) return rc;
+    }
+    int rc = wf_ensure(c, g.P, staging_elems, g.list_per_pipe * (size_t)g.K);
+    if (rc) return rc;
+    r.work_total = g.work_total; r.work_per_shard = g.work_per_shard;
+    r.work_left = true;
+    if (!r.live) {
+        r.K = g.K; r.P = g.P; r.Pp = g.Pp; r.list_cap = g.list_cap;
+        r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
+        r.serial = false;
+        r.prev = WfBatch();
+        r.cur = WfBatch{true, n, c->sample + n, 0u};
+        for (int p = 0; p < r.K; p++) {
+            r.pipes[p] = WfPipe();
+            WfParams &W = r.pipes[p].W;
+            W.sc = c->sc;
+            W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
+            W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
+            W.hit = c->w_hit.p; W.vis = c->w_vis.p;
+            for (int b = 0; b < 2; b++)
+                for (int k = 0; k < 4; k++)
+                    W.list[b][k] = c->w_list_ext.p + g.list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * g.list_cap * kWfShards;
+            W.staging[0] = c->w_staging[0].p; W.staging[1] = c->w_staging[1].p;
+            W.batch_parity = 0; W.keep_pool = 0;
+            W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
+            W.slot_base = g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
+            W.P = g.Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
+            W.band = c->band; W.stride = c->stride; W.phase = c->phase;
+            W.tiles_x = g.tiles_x; W.tiles_y = g.tiles_y; W.npix_padded = g.npix_padded; W.work_total = g.work_total;
+            W.work_per_shard = g.work_per_shard; W.list_cap = g.list_cap;
+            W.first_sample = c->sample + 1; W.n_samples = n;
+            W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
+            W.count = c->counting ? 1u : 0u;
+            W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
+            W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * 64u;
+            r.pipes[p].stream = (p == 0) ? c->stream : c->pipe_stream[p];
+            r.pipes[p].blocks_now = r.trace_blocks;
+        }
+        // fork: pipe 0's init resets the shared work queue; the other streams start after it
+        HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int p = 1; p < r.K; p++) {
+            HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
+            HIPCHK(c, wf_launch_init(r.pipes[p].W, r.pipes[p].stream));
+        }
+        // the first chunk of every pipe (from here on one chunk per pipe is always outstanding)
+        for (int p = 0; p < r.K; p++) { rc = wf_enqueue_chunk(c, p, 0); if (rc) return rc; }
+        r.live = true;
+    } else {
+        // The parked batch becomes the previous one: its last paths keep their slots (and their staging
+        // buffer) while this batch's work flows into the slots that are free.
+        r.prev = r.cur;
+        r.cur = WfBatch{true, n, c->sample + n, r.prev.parity ^ 1u};
+        for (int p = 0; p < r.K; p++) {
+            WfPipe &pp = r.pipes[p];
+            pp.W.first_sample = c->sample + 1; pp.W.n_samples = n;
+            pp.W.work_total = g.work_total; pp.W.work_per_shard = g.work_per_shard;
+            pp.W.batch_parity = r.cur.parity; pp.W.keep_pool = 1;
+            pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
+            pp.it_fresh = pp.it;
+            pp.old_clear = !r.prev.open;
+        }
+        // Every kernel enqueued so far still belongs to the parked batch (old parameters, an empty
+        // queue): the queue is refilled only after all of them, and nobody continues before it is.
+        for (int p = 1; p < r.K; p++) {
+            HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+        }
+        HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int p = 1; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
     }
     c->sample += n;
-    WfParams R = pipes[0].W;
-    HIPCHK(c, wf_launch_resolve(R, c->sample, c->stream));
-    c->last_launches += 2;
-    return CRT_OK;
+    return wf_drive(c, !defer);
 }
 
 }  // namespace
@@ -634,12 +777,15 @@ void crt_destroy(crt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    // parked work is abandoned, but every stream must have drained before the buffers go
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int p = 1; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
+    delete c->run;
     c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_lights.release(); c->w_overflow.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
-    c->w_nee.release(); c->w_staging.release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
+    c->w_nee.release(); c->w_staging[0].release(); c->w_staging[1].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
     c->w_vis.release(); c->w_list_ext.release(); c->w_list_sh.release(); c->w_wq.release();
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
         c->w_ctl[p].release();
@@ -671,6 +817,7 @@ int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const voi
     if (!(camera[11] >= 1.0f && camera[12] >= 1.0f && camera[11] <= 65536.0f && camera[12] <= 65536.0f))
         return fail(c, CRT_EINVAL, "crt_upload_scene: camera width/height (floats 11,12) must be 1..65536");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
     std::vector<HostPrim> prims(nprim), lts(nlight);
@@ -737,6 +884,7 @@ int crt_set_tile(crt_ctx *c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
     if (x0 > x1 || y0 > y1 || x1 > c->W || y1 > c->H)
         return fail(c, CRT_EINVAL, "crt_set_tile: rectangle [%u,%u)x[%u,%u) outside %ux%u", x0, x1, y0, y1, c->W, c->H);
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->x0 = x0; c->y0 = y0; c->tw = x1 - x0; c->th = y1 - y0;
     c->band = 0x40000000u; c->stride = 1; c->phase = 0;
@@ -753,6 +901,7 @@ int crt_set_row_bands(crt_ctx *c, uint32_t band_rows, uint32_t parts, uint32_t p
     if (band_rows == 0 || parts == 0 || part >= parts || band_rows > 65536u)
         return fail(c, CRT_EINVAL, "crt_set_row_bands: need band_rows >= 1 and part < parts");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint32_t rows = 0;                                   // rows y of the frame with (y / band) % parts == part
     for (uint32_t b = part; (unsigned long long)b * band_rows < c->H; b += parts)
@@ -771,6 +920,7 @@ int crt_build_accel(crt_ctx *c, int mode)
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_build_accel: upload a scene first");
     if (mode != CRT_ACCEL_NONE && mode != CRT_ACCEL_BVH2) return fail(c, CRT_EINVAL, "crt_build_accel: unknown mode %d", mode);
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return upload_geometry(c, mode);
 }
@@ -780,6 +930,7 @@ int crt_reset(crt_ctx *c)
     if (!c) return CRT_EINVAL;
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_reset: upload a scene first");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     return zero_state(c);
 }
 
@@ -798,7 +949,6 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
     P.tiles_x = (c->tw + 7) / 8; P.tiles_y = (c->th + 7) / 8;        // main.js:606-610
     c->last_launches = 0;
     c->last_timed = true;
-    c->last_trace_kernel_launches = 0;
     c->last_iterations = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t left = n_samples;
@@ -814,6 +964,7 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
             left -= n;
         }
     } else {
+        { int rc_ = wf_flush(c); if (rc_) return rc_; }
         uint32_t chunk = c->spp_per_launch ? c->spp_per_launch : 8u;
         while (left) {
             uint32_t n = std::min(left, chunk);
@@ -833,6 +984,7 @@ int crt_sync(crt_ctx *c)
 {
     if (!c) return CRT_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }
@@ -856,6 +1008,7 @@ int crt_read_accum(crt_ctx *c, float *out)
     if (!c || !out) return CRT_EINVAL;
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_accum: no scene");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(out, accum_ptr(c), n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -867,6 +1020,7 @@ int crt_read_rgba8(crt_ctx *c, uint8_t *out)
     if (!c || !out) return CRT_EINVAL;
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_rgba8: no scene");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(out, rgba_ptr(c), n * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -878,6 +1032,7 @@ int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
     if (!c || !in) return CRT_EINVAL;
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_write_accum: no scene");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(accum_ptr(c), in, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -900,6 +1055,7 @@ int crt_bind_output(crt_ctx *c, void *accum_dev, void *rgba8_dev)
     if (((uintptr_t)accum_dev & 15u) || ((uintptr_t)rgba8_dev & 3u))
         return fail(c, CRT_EINVAL, "crt_bind_output: accum must be 16-byte and rgba8 4-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->accum_bound = (float4 *)accum_dev;
     c->rgba_bound = (uchar4 *)rgba8_dev;
@@ -910,6 +1066,7 @@ int crt_set_stream(crt_ctx *c, void *hip_stream)
 {
     if (!c) return CRT_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return CRT_OK;
@@ -918,6 +1075,7 @@ int crt_set_stream(crt_ctx *c, void *hip_stream)
 int crt_enable_counters(crt_ctx *c, int on)
 {
     if (!c) return CRT_EINVAL;
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     c->counting = on != 0;
     return CRT_OK;
 }
@@ -942,6 +1100,7 @@ int crt_counters(crt_ctx *c, uint64_t out[CRT_NCOUNTERS])
 {
     if (!c || !out) return CRT_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipMemcpyAsync(out, c->d_counters.p, CRT_NCOUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
@@ -952,6 +1111,7 @@ int crt_last_trace_ms(crt_ctx *c, float *ms, uint32_t *launches)
     if (!c) return CRT_EINVAL;
     if (!c->last_timed) return fail(c, CRT_ESTATE, "crt_last_trace_ms: no crt_trace yet");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float t = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
@@ -966,17 +1126,20 @@ int crt_last_kernel_ms(crt_ctx *c, float *ms, uint32_t *launches)
     if (!c) return CRT_EINVAL;
     if (!c->last_timed) return fail(c, CRT_ESTATE, "crt_last_kernel_ms: no crt_trace yet");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float total = 0.0f;
     uint32_t n = 0;
     if (c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
         if (!c->time_kernels) return fail(c, CRT_ESTATE, "crt_last_kernel_ms: set option time_kernels=1 before crt_trace");
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         n = c->last_trace_kernel_launches;
         for (uint32_t i = 0; i < n; i++) {
             float t = 0.0f;
             HIPCHK(c, hipEventElapsedTime(&t, c->kev[2 * (size_t)i], c->kev[2 * (size_t)i + 1]));
             total += t;
         }
+        c->last_trace_kernel_launches = 0;               // the next query starts a new interval
     } else {
         HIPCHK(c, hipEventElapsedTime(&total, c->ev0, c->ev1));
         n = c->last_launches;
@@ -1002,6 +1165,8 @@ int crt_accel_stats(crt_ctx *c, uint64_t out[8])
 int crt_set_option(crt_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return CRT_EINVAL;
+    { int rc_ = wf_flush(c); if (rc_) return rc_; }
+    if (!std::strcmp(name, "wf_defer")) { c->wf_defer = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
     if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
@@ -1010,7 +1175,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }
-    if (!std::strcmp(name, "time_kernels")) { c->time_kernels = value != 0; return CRT_OK; }
+    if (!std::strcmp(name, "time_kernels")) { c->time_kernels = value != 0; c->last_trace_kernel_launches = 0; return CRT_OK; }
     return fail(c, CRT_EINVAL, "crt_set_option: unknown option '%s'", name);
 }
 

@@ -74,11 +74,12 @@ struct TraceParams {
 //   hit     (t, hit slot bits)            written by the trace kernel for extension rays
 //   vis     in: light primitive index, out: 1 = light visible    (shadow rays)
 //   list[parity][class]                   slots with an active ray this iteration (ballot/popc compacted)
-//   staging (xyz, -) per (sample, pixel)  finished samples, summed in sample order by k_wf_resolve
+//   staging[b] (xyz, -) per (sample, pixel)  finished samples of batch parity b, summed in sample order by k_wf_resolve
 constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
 // ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
 constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;
 constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
+constexpr uint32_t kWfBatchShift = 5;                           // 1 bit: which of the two batches in flight the path belongs to
 
 // Every queue counter is sharded kWfShards ways, one 128-byte line per shard: same-address
 // returning atomics serialize at ~11 ns each on gfx950, which at one atomic per wave would
@@ -86,7 +87,8 @@ constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits
 // the ray lists; traversal waves and re-arming waves pick a non-empty shard with one
 // wave-wide load + ballot.
 constexpr uint32_t kWfShards = 64;
-struct WfShard { uint32_t n[4], cur, pad[27]; };              // rays listed by shade per class / fetch cursor of trace
+// rays listed by shade per class / fetch cursor of trace / slots still alive for the PREVIOUS batch
+struct WfShard { uint32_t n[4], cur, old, pad[26]; };
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
@@ -106,7 +108,9 @@ struct WfParams {
     float2 *hit;
     uint32_t *vis;
     uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
-    float4 *staging;
+    float4 *staging[2];              // finished samples of the batch with parity 0 / 1 (two batches can be in flight)
+    uint32_t batch_parity;           // parity of the batch whose work queue is loaded (k_wf_resolve: the batch to resolve)
+    uint32_t keep_pool;              // k_wf_init: leave the slots and list counters alone (paths of the previous batch live on)
     WfCtl *ctl;
     WfWorkQ *wq;
     uint32_t slot_base;              // this pipe's slots are [slot_base, slot_base + P)

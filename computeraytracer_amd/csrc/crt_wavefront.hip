@@ -95,7 +95,7 @@ __device__ __forceinline__ void wavelengths_of(uint32_t lambda, uint32_t wl[4])
     wl[3] = (lambda + 12u) % kNLambda;                           // :321
 }
 
-struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary; };
+struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary, old; };
 struct ShadeCnt { uint32_t rays = 0, bounces = 0, shadow = 0, hits = 0, paths = 0, prims = 0, walk = 0; };
 
 // One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
@@ -292,7 +292,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             const uint32_t tile = pp >> 6, l = pp & 63u;
             const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
             f3 c = spectral_to_xyz(S, R.radiance, wl);
-            P.staging[(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
+            P.staging[(R.flags >> kWfBatchShift) & 1u][(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
             alive = false;
             if (COUNT) cn.paths++;
         }
@@ -365,7 +365,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                     R.beta = f4{1, 1, 1, 1}; R.radiance = f4{0, 0, 0, 0};
                     R.last_pdf = 1.0f; R.etaScale = 1.0f; R.exclude = 0xFFFFFFFFu;
                     R.work = (uint32_t)w;
-                    R.flags = kWfAlive | (lambda << kWfLambdaShift);
+                    R.flags = kWfAlive | (lambda << kWfLambdaShift) | (P.batch_parity << kWfBatchShift);
                     alive = true;
                     emit_ext = true;
                     ext_primary = true;
@@ -402,7 +402,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
         P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
     }
-    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary};
+    const bool old = alive && ((R.flags >> kWfBatchShift) & 1u) != P.batch_parity;
+    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, old};
 }
 
 template <bool COUNT>
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     WfCtl *ctl = P.ctl;
     if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
         WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
-        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
+        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0; nx.old = 0;
     }
     uint32_t slot, my_shard;
     bool in_pool;
@@ -452,9 +453,11 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         const bool cl0 = emit_ext && ext_primary, cl1 = emit_ext && !ext_primary;
         const bool cl2 = emit_sh && sh_primary, cl3 = emit_sh && !sh_primary;
         const unsigned long long m0 = __ballot(cl0), m1 = __ballot(cl1), m2 = __ballot(cl2), m3 = __ballot(cl3);
+        const unsigned long long mo = __ballot(so.old);          // paths of the previous batch still on their way
         WfShard &sh = ctl->shard[ring][my_shard];
         uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (lane == 0) {
+            if (mo) atomicAdd(&sh.old, (uint32_t)__popcll(mo));
             if (m0) b0 = atomicAdd(&sh.n[0], (uint32_t)__popcll(m0));
             if (m1) b1 = atomicAdd(&sh.n[1], (uint32_t)__popcll(m1));
             if (m2) b2 = atomicAdd(&sh.n[2], (uint32_t)__popcll(m2));
@@ -887,8 +890,9 @@ __global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t l
     if (pix >= npix) return;
     const float4 a4 = P.accum[pix];
     f3 acc = f3{a4.x, a4.y, a4.z};
+    const float4 *__restrict__ staging = P.staging[P.batch_parity];
     for (uint32_t s = 0; s < P.n_samples; s++) {
-        const float4 v = P.staging[(size_t)s * npix + pix];
+        const float4 v = staging[(size_t)s * npix + pix];
         acc = acc + f3{v.x, v.y, v.z};                           // :108, in sample order
     }
     P.accum[pix] = float4{acc.x, acc.y, acc.z, a4.w};
@@ -898,10 +902,11 @@ __global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t l
 __global__ void k_wf_init(const WfParams P)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < P.P) P.misc[P.slot_base + i] = uint4{0, 0, 0, 0};
+    if (i < P.P && !P.keep_pool) P.misc[P.slot_base + i] = uint4{0, 0, 0, 0};
     if (i < kWfShards) {
         WfCtl *c = P.ctl;
-        for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; }
+        if (!P.keep_pool)
+            for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
         if (P.reset_wq) {
             P.wq->work[i].cur = 0;
             if (i == 0) P.wq->work_done = 0;
@@ -912,7 +917,7 @@ __global__ void k_wf_init(const WfParams P)
 // ------------------------------------------------------------------ launchers
 hipError_t wf_launch_init(const WfParams &P, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_wf_init, dim3((P.P + 255) / 256), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_wf_init, dim3(P.keep_pool ? 1u : (P.P + 255) / 256), dim3(256), 0, s, P);
     return hipGetLastError();
 }
 

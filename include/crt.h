@@ -106,8 +106,18 @@ int crt_reset(crt_ctx *ctx);
 /* ~ n_samples iterations of frame() (main.js:597-611):
  *   { sample++ (UpdateVariables.wgsl) ; path-trace dispatch (ComputeShader.wgsl) }.
  * Samples are accumulated into alt_color_buffer in order; the rgba8
- * framebuffer holds the tone-mapped average after the last one. Asynchronous. */
+ * framebuffer holds the tone-mapped average after the last one.
+ * Asynchronous, and (option "wf_defer", default 1) PIPELINED across calls: a call
+ * returns once its samples' work queue is empty, while its last, longest paths are
+ * still in flight; they finish under the next crt_trace call, or in crt_sync.  So:
+ *   - after crt_sync (or any crt_read_*, crt_counters, crt_last_*_ms) the buffers
+ *     hold every sample requested so far;
+ *   - in between, buffers bound with crt_bind_output hold, in stream order, the
+ *     complete frame of an EARLIER crt_trace call (at least the one before the
+ *     last) -- never a half-resolved one.  A display/gather loop that shows frame
+ *     k-1 while frame k renders needs no sync at all. */
 int crt_trace(crt_ctx *ctx, uint32_t n_samples);
+/* Finish everything requested so far and wait for it. */
 int crt_sync(crt_ctx *ctx);
 
 /* Current value of the `sample` counter (ComputeShader.wgsl:3). */
@@ -139,19 +149,23 @@ int crt_enable_counters(crt_ctx *ctx, int on);
 int crt_counters(crt_ctx *ctx, uint64_t out[CRT_NCOUNTERS]);
 int crt_reset_counters(crt_ctx *ctx);
 
-/* Device time of the kernels enqueued by the LAST crt_trace call (HIP events
- * on the context's stream), and how many kernel launches that was. */
+/* Device time from the start of the LAST crt_trace call to the end of its work
+ * (HIP events on the context's stream; finishes the call's parked paths first),
+ * and how many kernel launches that was. */
 int crt_last_trace_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
 
-/* Device time of the DOMINANT kernel's launches inside the last crt_trace call, summed,
- * and their number: the BVH traversal kernel k_wf_trace of the wavefront pipeline (needs
- * option "time_kernels"=1, which brackets every launch with HIP events), or the single
- * trace kernel of the "pipeline"=0 form. */
+/* Device time of the DOMINANT kernel's launches, summed, and their number: the BVH traversal
+ * kernel k_wf_trace of the wavefront pipeline -- every launch since the previous query (or
+ * since option "time_kernels"=1 was set, which brackets each launch with HIP events on the
+ * stream it runs on) -- or the single trace kernel of the last crt_trace call in the
+ * "pipeline"=0 form.  Syncs. */
 int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
 
 /* Tuning knobs.  "spp_per_launch": samples fused per batch (0 = default);
  * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
- * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "time_kernels". */
+ * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "wf_pipes": half-pools
+ * on separate streams; "wf_defer": 0 = every crt_trace call runs its paths to the end;
+ * "time_kernels".  Setting an option first finishes what is in flight. */
 int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);
 
 /* Accel statistics: out[0]=BVH2 inner nodes, [1]=leaves, [2]=max depth, [3]=device bytes,

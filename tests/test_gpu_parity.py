@@ -335,6 +335,52 @@ def test_two_pipes_with_long_tails_repeatable(renderer, orc):
         renderer.enable_counters(False).set_option("wf_finish_at", 4096).set_option("wf_serial_tail", 0)
 
 
+def test_batches_pipelined_across_calls(renderer, orc):
+    """crt_trace calls end parked (the batch's last paths finish under the next call, or at sync).  Whatever
+    the interleaving -- parked or not, equal or changing batch sizes, two pipes or one, long glass-sphere
+    tails -- the frame after sync is the oracle's; and a buffer bound with bind_output holds, in stream
+    order and without any sync, a COMPLETE earlier frame."""
+    import torch
+    from computeraytracer_amd import cornell
+    ps = cornell(640, 640)                      # 410k pixels: pool = work, K = 2 at 2 spp
+    sc = orc.Scene.from_packed(ps)
+    frames = {n: sc.render(n)[:2] for n in (2, 4, 6, 8, 9)}
+    try:
+        for defer in (1, 0):
+            renderer.upload(ps).build_accel("bvh2").set_option("wf_defer", defer)
+            for _ in range(4):
+                renderer.frame(2)               # no sync in between
+            renderer.sync()
+            assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *frames[8])
+            renderer.frame(1).sync()            # a different batch size continues correctly
+            assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *frames[9])
+        # stream-ordered view of a bound output between calls
+        renderer.set_option("wf_defer", 1)
+        dev = torch.device("cuda", 0)
+        acc_t = torch.zeros((640, 640, 4), dtype=torch.float32, device=dev)
+        rgba_t = torch.zeros((640, 640, 4), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.Stream(device=dev)  # (the null stream's handle is 0, which means "the context's own")
+        torch.cuda.synchronize()
+        renderer.set_stream(stream.cuda_stream)
+        renderer.upload(ps).build_accel("bvh2").bind_output(acc_t.data_ptr(), rgba_t.data_ptr())
+        seen = []
+        with torch.cuda.stream(stream):
+            for k in range(1, 5):
+                renderer.frame(2)
+                seen.append((k, rgba_t.clone()))  # enqueued on the same stream, no sync with the renderer
+        renderer.sync()
+        torch.cuda.synchronize()
+        for k, snap in seen:
+            snap = snap.cpu().numpy()
+            ok = [j for j in range(max(1, k - 1), k + 1) if np.array_equal(snap, frames[2 * j][1])]
+            assert ok or (k == 1 and not snap.any()), f"after call {k} the bound framebuffer is neither frame {k - 1} nor frame {k}"
+        assert np.array_equal(rgba_t.cpu().numpy(), frames[8][1])
+        assert np.array_equal(bits(acc_t.cpu().numpy())[..., :3], bits(frames[8][0])[..., :3])
+    finally:
+        renderer.set_stream(None)
+        renderer.set_option("wf_defer", 1)
+
+
 def test_one_sample_per_pixel_and_tiny_tiles(renderer, orc):
     """Pool larger than the work (1 spp on a small tile) and a 1x1 tile."""
     from computeraytracer_amd import cornell
