@@ -28,7 +28,7 @@ hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out,
 hipError_t wf_launch_init(const WfParams &P, hipStream_t s);
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
-hipError_t wf_launch_finish(const WfParams &P, uint32_t it, hipStream_t s);
+hipError_t wf_launch_finish(const WfParams &P, uint32_t max_paths, hipStream_t s);
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
 }  // namespace crt
 
@@ -133,16 +133,18 @@ struct crt_ctx {
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
     int wf_defer = 1;               // 1: a batch ends parked, its last paths finish under the next batch (or at crt_sync)
+    int wf_tail_walk = 1;           // shade walks the ray lists once few paths are left
     WfRun *run = nullptr;           // pipeline state between calls
-    int wf_serial_tail = 0;         // 1: once a pipe reaches the tail, all pipes continue on one stream
-    uint32_t wf_finish_at = 4096;   // rays left (per pipe) at which k_wf_finish takes over; 0 = never
+    uint32_t wf_finish_at = 32768;  // paths of the previous batch left (per pipe) at which they move to the side pool; 0 = never
+    uint32_t wf_flush_at = 4096;    // the same for the LAST batch at crt_sync (nothing to hide its tail under); 0 = never
+    uint32_t wf_side_ppw = 64, wf_flush_ppw = 4;   // k_wf_finish: paths per wave, under the next batch / at crt_sync
     DevBuf<WfCtl> w_ctl[kMaxPipes];
     DevBuf<WfWorkQ> w_wq;
     WfWorkQ *h_wq[2] = {nullptr, nullptr};                 // pinned
     WfCtl *h_ctl[kMaxPipes][2] = {};                       // pinned, double-buffered status readbacks
     hipEvent_t ev_ctl[kMaxPipes][2] = {};
-    hipStream_t pipe_stream[kMaxPipes] = {};               // [0] unused: pipe 0 runs on the context's stream
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {};
+    hipStream_t pipe_stream[kMaxPipes] = {};               // the pipes' own streams (the context's stream only forks and resolves)
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {}, ev_evict[kMaxPipes] = {};
     bool time_kernels = false;
     std::vector<hipEvent_t> kev;    // event pairs around k_wf_trace launches
     float last_trace_kernel_ms = 0.0f;
@@ -369,7 +371,7 @@ int upload_geometry(crt_ctx *c, int mode)
 
 
 // ---------------------------------------------------------------- wavefront driver
-int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
+int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
 {
     if (c->w_list_ext.n < list_elems) HIPCHK(c, c->w_list_ext.alloc(list_elems));
     if (c->w_misc.n < P) {
@@ -392,7 +394,7 @@ int wf_ensure(crt_ctx *c, uint32_t P, size_t staging_elems, size_t list_elems)
                 HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl[p][b], hipEventDisableTiming));
             }
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[p], hipEventDisableTiming));
-            if (p > 0) HIPCHK(c, hipStreamCreateWithFlags(&c->pipe_stream[p], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_evict[p], hipEventDisableTiming));
         }
         for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[b], sizeof(WfWorkQ), hipHostMallocDefault));
     }
@@ -415,21 +417,22 @@ struct WfPipe {
     uint32_t it = 0, chunk = 4, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
     uint32_t it_fresh = 0;          // iterations >= it_fresh belong to the batch whose work queue is loaded
     int cur = 0;                    // status buffer of the chunk that is outstanding between driver passes
-    bool done = false;              // no more chunks are enqueued for this pipe (drained, finished or parked)
-    bool old_clear = true;          // no path of the previous batch is alive in this pipe any more
-    unsigned long long rays = 0;    // rays listed by the last iteration whose status was read
+    bool done = false;              // no more chunks are enqueued for this pipe (drained, evicted or parked)
+    bool fresh = false;             // a status of the loaded batch has been read
+    unsigned long long rays = 0, old = 0;   // from the last status read: rays listed / paths of the previous batch alive
+    uint32_t evict_next = 0;        // evict_mask for the first shade launch of the next chunk
 };
 
-// A batch of samples whose paths are (or may still be) in the pool; `open` until k_wf_resolve has been
-// enqueued for it.
+// A batch of samples whose paths are (or may still be) in flight; `open` until k_wf_resolve is enqueued for it.
 struct WfBatch { bool open = false; uint32_t n = 0, last_sample = 0, parity = 0; };
 
-// The pipeline's state between driver calls.  A batch normally ENDS PARKED: its work queue is empty
-// but its last, long paths are still in the pool, one chunk of iterations is still enqueued, and the
-// next batch's work flows into the slots as they free up -- the path-length tail of one batch is
-// hidden under the bulk of the next instead of running on a nearly empty GPU.  wf_flush() runs the
-// stragglers to the end (tail mode, k_wf_finish) and resolves; every call that reads or changes state
-// flushes first.
+// The pipeline's state between driver calls.  A batch normally ENDS PARKED: its work queue is empty, its
+// paths are still in the pool, one chunk of iterations is still enqueued -- and the next batch's work flows
+// into the slots as they free up, so the pool never runs dry between batches.  Once only a few paths of the
+// parked batch are left, k_wf_shade moves them to the side pool, k_wf_finish runs them to their end on the
+// side stream and the batch is resolved: the path-length tail of a batch runs under the bulk of the next
+// one instead of on a nearly empty GPU.  wf_flush() does the same for the last batch (there is nothing to
+// hide it under); every call that reads or changes state flushes first.
 struct WfRun {
     bool live = false;              // pipes are forked; every pipe has one outstanding chunk in status buffer [cur]
     int K = 0;
@@ -437,7 +440,9 @@ struct WfRun {
     unsigned long long work_total = 0;
     WfPipe pipes[crt_ctx::kMaxPipes];
     WfBatch cur, prev;
-    bool work_left = false, serial = false;
+    bool work_left = false;
+    uint32_t rate_it = 0;                   // pipe 0's iteration and the work consumed at its last status
+    unsigned long long rate_consumed = 0;
 };
 
 struct WfConfig {
@@ -489,13 +494,18 @@ int wf_resolve_batch(crt_ctx *c, WfBatch &b)
 // Iterations are enqueued in chunks; after each chunk the small control blocks are copied back
 // (asynchronously) so the host can tell how far the pool has drained.  One chunk is always
 // enqueued AHEAD of the status being waited for, so the GPU never idles on the host; the
-// price is at most one chunk of empty iterations at the end.
+// price is at most one chunk of nearly empty iterations at the end.
 int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
 {
     WfPipe &pp = c->run->pipes[p];
     pp.W.tail_bound = pp.tail_bound;
     for (uint32_t k = 0; k < pp.chunk; k++, pp.it++) {
+        pp.W.evict_mask = pp.evict_next;
         HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
+        if (pp.evict_next) {                                     // the side stream may start once this launch is through
+            HIPCHK(c, hipEventRecord(c->ev_evict[p], pp.stream));
+            pp.evict_next = 0; pp.W.evict_mask = 0;
+        }
         if (c->time_kernels) {
             size_t need = 2 * (size_t)(c->last_trace_kernel_launches + 1);
             while (c->kev.size() < need) {
@@ -520,17 +530,39 @@ int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
     return CRT_OK;
 }
 
+// After every pipe's evicting shade launch, run the evicted paths of batch `b` to their end and resolve the
+// batch -- on the context's stream, which has nothing else to do while the pipes work (a stream of its own
+// would be a fifth one, and streams beyond the hardware queues share one: a pipe queued behind a wait stalls).
+int wf_finish_side(crt_ctx *c, WfBatch &b, uint32_t max_paths, uint32_t paths_per_wave)
+{
+    WfRun &r = *c->run;
+    for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_evict[p], 0));
+    for (int p = 0; p < r.K; p++) {
+        WfParams F = r.pipes[p].W;
+        F.batch_parity = b.parity;
+        F.tail_bound = paths_per_wave;
+        HIPCHK(c, wf_launch_finish(F, max_paths, c->stream));
+        c->last_launches++;
+    }
+    return wf_resolve_batch(c, b);
+}
+
 // Enqueue iterations and read statuses until the loaded batch is parked (to_end = false: its queue is
 // empty and the previous batch is resolved) or finished and resolved (to_end = true).
 int wf_drive(crt_ctx *c, bool to_end)
 {
     WfRun &r = *c->run;
     const int K = r.K;
+    const unsigned long long evict_at = std::min<unsigned long long>(c->wf_finish_at, kWfSideCap);
+    const unsigned long long flush_at = std::min<unsigned long long>(c->wf_flush_at, kWfSideCap);
     int active = 0;
     for (int p = 0; p < K; p++) { r.pipes[p].done = false; active++; }
+    bool prev_evicting = false, cur_evicting = false;
     while (active > 0) {
         for (int p = 0; p < K; p++)
             if (!r.pipes[p].done) { int rc = wf_enqueue_chunk(c, p, r.pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
+        // the chunk just enqueued carried the eviction of the previous batch's last paths: finish and resolve it
+        if (prev_evicting) { int rc = wf_finish_side(c, r.prev, kWfSideCap, c->wf_side_ppw); if (rc) return rc; prev_evicting = false; }
         for (int p = 0; p < K; p++) {
             WfPipe &pp = r.pipes[p];
             if (pp.done) continue;
@@ -544,56 +576,45 @@ int wf_drive(crt_ctx *c, bool to_end)
                     if (c->h_wq[pp.cur]->work[sidx].cur < size) left = true;
                 }
                 r.work_left = left;                              // monotone within a batch: once false it stays false
+                // Chunks shrink as the queue runs dry: what is enqueued ahead of the status that shows it empty
+                // runs on a nearly empty pool, and the host needs only ~20 us per launch to keep up.
+                unsigned long long consumed = 0;
+                for (uint32_t sidx = 0; sidx < kWfShards; sidx++) consumed += std::min<unsigned long long>(c->h_wq[pp.cur]->work[sidx].cur, r.work_per_shard);
+                consumed = std::min(consumed, r.work_total);
+                const uint32_t its = pp.it_end[pp.cur] - r.rate_it;
+                if (its > 0 && consumed > r.rate_consumed) {
+                    const unsigned long long per_it = (consumed - r.rate_consumed) / its;
+                    const unsigned long long left_its = (r.work_total - consumed) / std::max<unsigned long long>(per_it, 1);
+                    const uint32_t chunk = left_its >= 16 ? 4u : left_its >= 6 ? 2u : 1u;
+                    for (int q = 0; q < K; q++) r.pipes[q].chunk = chunk;
+                }
+                r.rate_it = pp.it_end[pp.cur]; r.rate_consumed = consumed;
             }
             const WfCtl *hc = c->h_ctl[p][pp.cur];
             unsigned long long rays = 0, old = 0;
             uint32_t bound = 0;
             for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
                 const WfShard &sh = hc->shard[(pp.it_end[pp.cur] - 1) & 3u][sidx];
-                // per-shard bound for later iterations: slots never change shard and none are re-armed in the
-                // tail, so no list of a shard can ever grow beyond the slots alive in it now
+                // per-shard bound for later iterations: slots never change shard and none are re-armed once the
+                // queue is empty, so no list of a shard can ever grow beyond the slots alive in it now
                 uint32_t alive_here = 0;
                 for (int k = 0; k < 4; k++) { rays += sh.n[k]; alive_here += sh.n[k]; }
                 bound = std::max(bound, alive_here);
                 old += sh.old;
             }
-            pp.rays = rays;
-            if (old == 0) pp.old_clear = true;                   // (paths of the previous batch cannot start any more)
+            pp.rays = rays; pp.old = old; pp.fresh = true;
             if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu old %llu work_left %d bound %u\n", p, pp.it_end[pp.cur], rays, old, (int)r.work_left, bound);
             // pipe 0's view of the queue can lag the others by a chunk; a pipe with no rays while work
             // may be left simply keeps going (its dead slots re-arm as soon as they see work)
-            if (!r.work_left && rays == 0) { pp.done = true; pp.old_clear = true; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
+            if (!r.work_left && rays == 0) { pp.done = true; pp.old = 0; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
             if (!to_end) {
                 // Park: the queue is empty and the batch before this one is resolved.  The chunk already
                 // enqueued ahead keeps the GPU busy until the next batch's work arrives.
                 if (!r.work_left && !r.prev.open) { pp.done = true; pp.cur ^= 1; active--; continue; }
-            } else {
-                if (!r.work_left && rays <= c->wf_finish_at && (r.serial || !c->wf_serial_tail)) {
-                    // A few paths left: one kernel runs them to the end (ray counts only shrink from here, so
-                    // `bound` also covers the chunk already enqueued ahead).
-                    pp.W.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
-                    HIPCHK(c, wf_launch_finish(pp.W, pp.it, pp.stream));
-                    c->last_launches++;
-                    pp.rays = 0;
-                    pp.done = true; pp.old_clear = true; pp.cur ^= 1; active--;
-                    continue;
-                }
-                if (!r.work_left && rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull)) {
+            } else if (!r.work_left && !cur_evicting) {
+                if (rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull) && c->wf_tail_walk) {
                     // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
                     // the ray lists instead of the whole pool and the grids shrink.
-                    // wf_serial_tail = 1 joins every pipe onto the context's stream from here on (a debugging
-                    // aid: it is how the double visit of a slot by the list-walking shade was told apart from
-                    // a coherence problem); by default the pipes stay concurrent, which is
-                    // worth ~1 ms per batch.
-                    if (!r.serial && c->wf_serial_tail) {
-                        r.serial = true;
-                        for (int q = 1; q < K; q++) {
-                            if (r.pipes[q].stream == c->stream) continue;
-                            HIPCHK(c, hipEventRecord(c->ev_join[q], r.pipes[q].stream));
-                            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[q], 0));
-                            r.pipes[q].stream = c->stream;
-                        }
-                    }
                     pp.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
                     pp.blocks_now = (uint32_t)std::min<unsigned long long>(r.trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
                 }
@@ -601,24 +622,65 @@ int wf_drive(crt_ctx *c, bool to_end)
             if (pp.it - pp.it_fresh > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
             pp.cur ^= 1;
         }
-        // the previous batch's last paths are through (every pipe said so, or is empty): its frame can be resolved
-        if (r.prev.open) {
-            bool clear = true;
-            for (int p = 0; p < K; p++) clear = clear && r.pipes[p].old_clear;
-            if (clear) { int rc = wf_resolve_batch(c, r.prev); if (rc) return rc; }
+        // Few paths of the previous batch are left in the pool (alive slots only shrink, so they still fit when
+        // the launch runs): the next shade launch of every pipe moves them to the side pool.
+        if (r.prev.open && !prev_evicting && active > 0) {
+            bool all_fresh = true;
+            unsigned long long old = 0, old_max = 0;
+            for (int p = 0; p < K; p++) {
+                const WfPipe &pp = r.pipes[p];
+                if (pp.done) continue;                           // (a drained pipe holds no path at all)
+                all_fresh = all_fresh && pp.fresh; old += pp.old; old_max = std::max(old_max, pp.old);
+            }
+            if (all_fresh && old == 0) { int rc = wf_resolve_batch(c, r.prev); if (rc) return rc; }
+            else if (all_fresh && old_max <= kWfSideCap && old <= evict_at * (unsigned)K) {
+                for (int p = 0; p < K; p++) if (!r.pipes[p].done) r.pipes[p].evict_next = 1u << r.prev.parity;
+                prev_evicting = true;
+            }
+        }
+        // to_end: once few paths are left altogether, everything alive goes to the side pool and the pool is done
+        if (to_end && !r.work_left && !cur_evicting && !prev_evicting && active > 0 && flush_at > 0) {
+            bool all_fresh = true, few = true;
+            for (int p = 0; p < K; p++) {
+                if (r.pipes[p].done) continue;
+                all_fresh = all_fresh && r.pipes[p].fresh; few = few && r.pipes[p].rays <= flush_at;
+            }
+            if (all_fresh && few) {
+                for (int p = 0; p < K; p++) {
+                    WfPipe &pp = r.pipes[p];
+                    if (pp.done) continue;
+                    pp.evict_next = 3u;
+                    const uint32_t chunk = pp.chunk;
+                    pp.chunk = 1;                                // one more iteration: its shade launch empties the pool
+                    int rc = wf_enqueue_chunk(c, p, pp.cur ^ 1);
+                    pp.chunk = chunk;
+                    if (rc) return rc;
+                    pp.done = true; pp.rays = 0; pp.cur ^= 1;
+                }
+                active = 0;
+                cur_evicting = true;
+            }
         }
     }
     bool empty = true;
     for (int p = 0; p < K; p++) empty = empty && r.pipes[p].rays == 0;
     if (to_end || empty) {
-        // everything enqueued for the other pipes comes before the resolve pass on the context's stream
-        for (int p = 1; p < K; p++) {
-            if (r.pipes[p].stream == c->stream) continue;
-            HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+        if (cur_evicting) {
+            // (nothing else is running: few paths per wave end sooner)
+            int rc = r.prev.open ? wf_finish_side(c, r.prev, kWfSideCap, c->wf_flush_ppw) : CRT_OK;
+            if (rc == CRT_OK) rc = wf_finish_side(c, r.cur, (uint32_t)std::min<unsigned long long>(kWfSideCap, flush_at), c->wf_flush_ppw);
+            if (rc) return rc;
+        } else {
+            // everything enqueued for the pipes comes before the resolve pass on the context's stream
+            for (int p = 0; p < K; p++) {
+                HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+            }
+            int rc = wf_resolve_batch(c, r.prev);
+            if (rc) return rc;
+            rc = wf_resolve_batch(c, r.cur);
+            if (rc) return rc;
         }
-        int rc = wf_resolve_batch(c, r.prev);
-        if (rc) return rc;
         if (c->counting) {
             // fold the pipes' counters into the context's
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -632,10 +694,15 @@ int wf_drive(crt_ctx *c, bool to_end)
             }
             HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
         }
-        rc = wf_resolve_batch(c, r.cur);
-        if (rc) return rc;
     }
-    if (to_end) r.live = false;      // the pool is empty; the next batch sets the pipes up afresh
+    if (to_end) {
+        // the pool is empty; the next batch sets the pipes up afresh (after everything enqueued here)
+        for (int p = 0; p < K; p++) {
+            HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+        }
+        r.live = false;
+    }
     return CRT_OK;
 }
 
@@ -660,20 +727,22 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     // counting folds counters on the host after every batch; otherwise batches end parked
     const bool defer = c->wf_defer && !c->counting;
     const size_t staging_elems = (size_t)n * g.npix;
+    const uint32_t side_slots = 2u * (uint32_t)crt_ctx::kMaxPipes * kWfSideCap;   // side pools first, then the pool
     if (r.live && (g.K != r.K || g.Pp != r.Pp || c->w_staging[0].n < staging_elems || r.prev.open)) {
         int rc = wf_flush(c);
         if (rc) return rc;
     }
-    int rc = wf_ensure(c, g.P, staging_elems, g.list_per_pipe * (size_t)g.K);
+    int rc = wf_ensure(c, (size_t)g.P + side_slots, staging_elems, g.list_per_pipe * (size_t)g.K);
     if (rc) return rc;
     r.work_total = g.work_total; r.work_per_shard = g.work_per_shard;
     r.work_left = true;
+    r.rate_consumed = 0;
     if (!r.live) {
         r.K = g.K; r.P = g.P; r.Pp = g.Pp; r.list_cap = g.list_cap;
         r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
-        r.serial = false;
         r.prev = WfBatch();
         r.cur = WfBatch{true, n, c->sample + n, 0u};
+        r.rate_it = 0;
         for (int p = 0; p < r.K; p++) {
             r.pipes[p] = WfPipe();
             WfParams &W = r.pipes[p].W;
@@ -685,9 +754,10 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
                 for (int k = 0; k < 4; k++)
                     W.list[b][k] = c->w_list_ext.p + g.list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * g.list_cap * kWfShards;
             W.staging[0] = c->w_staging[0].p; W.staging[1] = c->w_staging[1].p;
-            W.batch_parity = 0; W.keep_pool = 0;
+            W.batch_parity = 0; W.keep_pool = 0; W.evict_mask = 0;
+            for (uint32_t b = 0; b < 2; b++) W.side_base[b] = (b * (uint32_t)crt_ctx::kMaxPipes + (uint32_t)p) * kWfSideCap;
             W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
-            W.slot_base = g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
+            W.slot_base = side_slots + g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
             W.P = g.Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
             W.band = c->band; W.stride = c->stride; W.phase = c->phase;
             W.tiles_x = g.tiles_x; W.tiles_y = g.tiles_y; W.npix_padded = g.npix_padded; W.work_total = g.work_total;
@@ -697,22 +767,33 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.count = c->counting ? 1u : 0u;
             W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
             W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * 64u;
-            r.pipes[p].stream = (p == 0) ? c->stream : c->pipe_stream[p];
+            if (!c->pipe_stream[p]) {
+                // Streams beyond the hardware queues (4 by default) share one, and two pipes sharing a queue do not
+                // overlap at all (measured: 95 instead of 77 ms per S2 frame when the caller's framework had taken
+                // the queues first).  The runtime keeps separate queues per priority level and frameworks create
+                // their stream pools at the default level, so the pipes take the high one -- all of them the same,
+                // an uneven pair measured 4-9 % slower.
+                int least = 0, greatest = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->pipe_stream[p], hipStreamNonBlocking, greatest));
+            }
+            r.pipes[p].stream = c->pipe_stream[p];
             r.pipes[p].blocks_now = r.trace_blocks;
         }
-        // fork: pipe 0's init resets the shared work queue; the other streams start after it
+        // The context's stream is the control stream: it resets the work queue and forks the pipes (and,
+        // later, resolves).  The pipes run on their own streams.
         HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        for (int p = 1; p < r.K; p++) {
+        for (int p = 0; p < r.K; p++) {
             HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
-            HIPCHK(c, wf_launch_init(r.pipes[p].W, r.pipes[p].stream));
+            if (p > 0) HIPCHK(c, wf_launch_init(r.pipes[p].W, r.pipes[p].stream));
         }
         // the first chunk of every pipe (from here on one chunk per pipe is always outstanding)
         for (int p = 0; p < r.K; p++) { rc = wf_enqueue_chunk(c, p, 0); if (rc) return rc; }
         r.live = true;
     } else {
-        // The parked batch becomes the previous one: its last paths keep their slots (and their staging
-        // buffer) while this batch's work flows into the slots that are free.
+        // The parked batch becomes the previous one: its paths keep their slots (and their staging buffer)
+        // while this batch's work flows into the slots that are free.
         r.prev = r.cur;
         r.cur = WfBatch{true, n, c->sample + n, r.prev.parity ^ 1u};
         for (int p = 0; p < r.K; p++) {
@@ -722,17 +803,18 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             pp.W.batch_parity = r.cur.parity; pp.W.keep_pool = 1;
             pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
             pp.it_fresh = pp.it;
-            pp.old_clear = !r.prev.open;
+            pp.fresh = false; pp.old = 0; pp.evict_next = 0; pp.chunk = 4;
         }
+        r.rate_it = r.pipes[0].it;
         // Every kernel enqueued so far still belongs to the parked batch (old parameters, an empty
         // queue): the queue is refilled only after all of them, and nobody continues before it is.
-        for (int p = 1; p < r.K; p++) {
+        for (int p = 0; p < r.K; p++) {
             HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
         }
-        HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
+        for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->stream));   // (one block each: queue + side counters)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        for (int p = 1; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
+        for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
     }
     c->sample += n;
     return wf_drive(c, !defer);
@@ -779,7 +861,8 @@ void crt_destroy(crt_ctx *c)
     (void)hipSetDevice(c->device);
     // parked work is abandoned, but every stream must have drained before the buffers go
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int p = 1; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
+    for (int p = 0; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
+
     delete c->run;
     c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_lights.release(); c->w_overflow.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
@@ -795,9 +878,11 @@ void crt_destroy(crt_ctx *c)
         }
         if (c->pipe_stream[p]) (void)hipStreamDestroy(c->pipe_stream[p]);
         if (c->ev_join[p]) (void)hipEventDestroy(c->ev_join[p]);
+        if (c->ev_evict[p]) (void)hipEventDestroy(c->ev_evict[p]);
     }
     for (int b = 0; b < 2; b++) if (c->h_wq[b]) (void)hipHostFree(c->h_wq[b]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1171,11 +1256,25 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
     if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
     if (!std::strcmp(name, "wf_finish_at")) { c->wf_finish_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
-    if (!std::strcmp(name, "wf_serial_tail")) { c->wf_serial_tail = value != 0; return CRT_OK; }
+    if (!std::strcmp(name, "wf_flush_at")) { c->wf_flush_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
+    if (!std::strcmp(name, "wf_side_ppw")) { c->wf_side_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_flush_ppw")) { c->wf_flush_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_tail_walk")) { c->wf_tail_walk = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }
-    if (!std::strcmp(name, "time_kernels")) { c->time_kernels = value != 0; c->last_trace_kernel_launches = 0; return CRT_OK; }
+    if (!std::strcmp(name, "time_kernels")) {
+        // value > 1 also creates the event pairs for that many launches now (event creation costs ~10 us apiece,
+        // which would otherwise land in the region being timed)
+        c->time_kernels = value != 0; c->last_trace_kernel_launches = 0;
+        HIPCHK(c, hipSetDevice(c->device));
+        while (value > 1 && c->kev.size() < 2 * (size_t)std::min<int64_t>(value, 1 << 20)) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->kev.push_back(e);
+        }
+        return CRT_OK;
+    }
     return fail(c, CRT_EINVAL, "crt_set_option: unknown option '%s'", name);
 }
 

@@ -25,6 +25,7 @@
 // consumes no random numbers, so a diffuse bounce can draw its light, hemisphere
 // and roulette numbers in one go.
 #include "crt_shade.h"
+#include <algorithm>
 
 namespace crt {
 
@@ -443,6 +444,30 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
             in_pool = !(entry & kWfListAlsoExt);                 // else reached through its extension ray
         }
     }
+    if (P.evict_mask) {
+        // Move the (few) paths of the batches named by evict_mask out of the pool: their rays of the last
+        // iteration are traced, so the slot state is complete; k_wf_finish continues them from the side pool.
+        // The slot is then dead and is re-armed below like any other.
+        uint4 misc = uint4{0, 0, 0, 0};
+        if (in_pool) misc = P.misc[slot];
+        const uint32_t par = (misc.y >> kWfBatchShift) & 1u;
+        const bool go = in_pool && (misc.y & kWfAlive) && ((P.evict_mask >> par) & 1u);
+        for (uint32_t b = 0; b < 2u; b++) {
+            const unsigned long long m = __ballot(go && par == b);
+            if (!m) continue;
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(&ctl->side_count[b], (uint32_t)__popcll(m));
+            base = __shfl(base, 0, 64);
+            const uint32_t idx = base + prefix_popc(m, lane_id());
+            if (go && par == b && idx < kWfSideCap) {            // (the host asks only when everything fits)
+                const uint32_t d = P.side_base[b] + idx;
+                P.ray_o[d] = P.ray_o[slot]; P.ray_d[d] = P.ray_d[slot]; P.sh_d[d] = P.sh_d[slot]; P.beta[d] = P.beta[slot];
+                P.radiance[d] = P.radiance[slot]; P.nee[d] = P.nee[slot]; P.rng[d] = P.rng[slot]; P.hit[d] = P.hit[slot];
+                P.vis[d] = P.vis[slot]; P.misc[d] = misc;
+                P.misc[slot] = uint4{0, 0, 0, 0};
+            }
+        }
+    }
     ShadeCnt cn;
     const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, my_shard, cn);
     const bool emit_ext = so.emit_ext, ext_primary = so.ext_primary, emit_sh = so.emit_sh, sh_primary = so.sh_primary;
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         const bool cl0 = emit_ext && ext_primary, cl1 = emit_ext && !ext_primary;
         const bool cl2 = emit_sh && sh_primary, cl3 = emit_sh && !sh_primary;
         const unsigned long long m0 = __ballot(cl0), m1 = __ballot(cl1), m2 = __ballot(cl2), m3 = __ballot(cl3);
-        const unsigned long long mo = __ballot(so.old);          // paths of the previous batch still on their way
+        const unsigned long long mo = __ballot(so.old);          // paths of the previous batch still in the pool
         WfShard &sh = ctl->shard[ring][my_shard];
         uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (lane == 0) {
@@ -814,32 +839,28 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
 // any-hit for the shadow ray), shade, repeat -- so the tail costs one ray latency per bounce
 // instead of two kernel launches per bounce.  Slots come from the previous iteration's ray lists
 // exactly as in k_wf_shade's tail mode.
+// ------------------------------------------------------------------ stragglers
+// k_wf_finish: one lane per side-pool path, run to the path's end (shade step, then trace what it emits,
+// ...) with the single-ray BVH2 walk.  Runs on its own stream while the pool works on the next batch.
 template <bool COUNT>
-__global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, uint32_t it)
+__global__ __launch_bounds__(64) void k_wf_finish(const WfParams P)
 {
     __shared__ int lds_stack[kStackDepth * 64];
     const DevScene &S = P.sc;
     WfCtl *ctl = P.ctl;
     int *stk = lds_stack + lane_id();
-    const uint32_t lbuf = it & 1u;
-    const uint32_t bps = (4u * P.tail_bound + 63u) / 64u;
-    const uint32_t my_shard = blockIdx.x / bps;
-    const uint32_t j = (blockIdx.x % bps) * 64u + threadIdx.x;
-    const WfShard &pv = ctl->shard[(it + 3u) & 3u][my_shard];
-    const size_t region = (size_t)my_shard * P.list_cap;
-    uint32_t slot = 0;
-    bool mine = false;
-    const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
-    if (cls < 4u && e < pv.n[cls]) {
-        const uint32_t entry = P.list[lbuf ^ 1u][cls][region + e];
-        slot = entry & kWfListSlot;
-        mine = !(entry & kWfListAlsoExt);                               // else reached through its extension ray
-    }
+    const uint32_t my_shard = 0;
+    // P.tail_bound = paths per wave: a wave runs until its longest path ends and every bounce costs the
+    // slowest lane's walk, so when the GPU has nothing else to do few paths per wave finish sooner
+    const uint32_t j = blockIdx.x * P.tail_bound + threadIdx.x;
+    const uint32_t count = min(ctl->side_count[P.batch_parity], kWfSideCap);
+    const bool mine = threadIdx.x < P.tail_bound && j < count;
+    const uint32_t slot = P.side_base[P.batch_parity] + (mine ? j : 0u);
     uint32_t flags = 0;
     if (mine) flags = P.misc[slot].y;
     bool alive = mine && (flags & kWfAlive);
-    // The rays these slots listed in iteration it-1 were already traced by k_wf_trace(it-1): start with
-    // the shade step; from then on this lane traces what its own shade steps emit.
+    // The rays these paths listed in their last pool iteration were traced there: start with the shade
+    // step; from then on this lane traces what its own shade steps emit.
     bool pend_sh = false, pend_ext = false;
     ShadeCnt cn;
     uint32_t c_nodes = 0, c_prims = 0;
@@ -907,6 +928,7 @@ __global__ void k_wf_init(const WfParams P)
         WfCtl *c = P.ctl;
         if (!P.keep_pool)
             for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
+        if (i == 0) { c->side_count[P.batch_parity] = 0; if (!P.keep_pool) c->side_count[P.batch_parity ^ 1u] = 0; }
         if (P.reset_wq) {
             P.wq->work[i].cur = 0;
             if (i == 0) P.wq->work_done = 0;
@@ -939,12 +961,13 @@ hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks
     return hipGetLastError();
 }
 
-hipError_t wf_launch_finish(const WfParams &P, uint32_t it, hipStream_t s)
+hipError_t wf_launch_finish(const WfParams &P, uint32_t max_paths, hipStream_t s)
 {
-    if (P.tail_bound == 0u) return hipErrorInvalidValue;
-    const uint32_t bps = (4u * P.tail_bound + 63u) / 64u;
-    if (P.count) hipLaunchKernelGGL((k_wf_finish<true>), dim3(kWfShards * bps), dim3(64), 0, s, P, it);
-    else hipLaunchKernelGGL((k_wf_finish<false>), dim3(kWfShards * bps), dim3(64), 0, s, P, it);
+    if (P.tail_bound == 0u || P.tail_bound > 64u) return hipErrorInvalidValue;     // paths per wave
+    const uint32_t blocks = (std::min(max_paths, kWfSideCap) + P.tail_bound - 1u) / P.tail_bound;
+    if (blocks == 0) return hipSuccess;
+    if (P.count) hipLaunchKernelGGL((k_wf_finish<true>), dim3(blocks), dim3(64), 0, s, P);
+    else hipLaunchKernelGGL((k_wf_finish<false>), dim3(blocks), dim3(64), 0, s, P);
     return hipGetLastError();
 }
 

@@ -156,8 +156,8 @@ int crt_last_trace_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
 
 /* Device time of the DOMINANT kernel's launches, summed, and their number: the BVH traversal
  * kernel k_wf_trace of the wavefront pipeline -- every launch since the previous query (or
- * since option "time_kernels"=1 was set, which brackets each launch with HIP events on the
- * stream it runs on) -- or the single trace kernel of the last crt_trace call in the
+ * since option "time_kernels" was set: 1 brackets each launch with HIP events on the
+ * stream it runs on, N > 1 also creates the event pairs for N launches up front) -- or the single trace kernel of the last crt_trace call in the
  * "pipeline"=0 form.  Syncs. */
 int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
 

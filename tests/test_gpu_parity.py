@@ -320,26 +320,27 @@ def test_two_pipes_with_long_tails_repeatable(renderer, orc):
     ray AND a shadow ray appears twice; the thread holding the shadow entry once looked at the slot's flags
     to find out -- flags that the thread holding the extension entry rewrites in the same launch.  With two
     pipes on two streams (block start times spread out) that gave tens of wrong pixels per frame.  Must be
-    bit-exact every time: streams joined in the tail or not, with and without the finish kernel."""
+    bit-exact every time: list-walking shade or not, stragglers moved to the side pool (k_wf_evict +
+    k_wf_finish) early, late or never, counting kernels or not."""
     from computeraytracer_amd import cornell
     ps = cornell()
     acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(2)
     try:
-        for serial_tail, finish_at, count in [(0, 0, True), (0, 4096, True), (0, 4096, False), (1, 4096, False), (1, 0, True)]:
-            renderer.set_option("wf_finish_at", finish_at).set_option("wf_pipes", 2).set_option("wf_serial_tail", serial_tail)
+        for tail_walk, finish_at, count in [(1, 0, True), (1, 4096, True), (1, 32768, False), (0, 0, False), (0, 65536, True)]:
+            renderer.set_option("wf_finish_at", finish_at).set_option("wf_pipes", 2).set_option("wf_tail_walk", tail_walk)
             for _ in range(3):
                 renderer.upload(ps).build_accel("bvh2").enable_counters(count).reset_counters()
                 renderer.frame(2).sync()
                 assert_same_image(renderer.read_accum(), renderer.read_rgba8(), acc_o, rgba_o)
     finally:
-        renderer.enable_counters(False).set_option("wf_finish_at", 4096).set_option("wf_serial_tail", 0)
+        renderer.enable_counters(False).set_option("wf_finish_at", 32768).set_option("wf_tail_walk", 1)
 
 
 def test_batches_pipelined_across_calls(renderer, orc):
-    """crt_trace calls end parked (the batch's last paths finish under the next call, or at sync).  Whatever
-    the interleaving -- parked or not, equal or changing batch sizes, two pipes or one, long glass-sphere
-    tails -- the frame after sync is the oracle's; and a buffer bound with bind_output holds, in stream
-    order and without any sync, a COMPLETE earlier frame."""
+    """crt_trace returns with the batch's last paths still running on the side stream (under the next call's
+    pool work) and its resolve pass still to come.  Whatever the interleaving -- deferred or not, equal or
+    changing batch sizes, long glass-sphere tails -- the frame after sync is the oracle's; and a buffer
+    bound with bind_output holds, in stream order and without any sync, a COMPLETE earlier frame."""
     import torch
     from computeraytracer_amd import cornell
     ps = cornell(640, 640)                      # 410k pixels: pool = work, K = 2 at 2 spp
