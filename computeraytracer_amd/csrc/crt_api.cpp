@@ -94,12 +94,14 @@ struct crt_ctx {
     Bvh bvh;
     Bvh4 bvh4;
     Bvh4Q bvh4q;
+    Bvh8Q bvh8q;
     int quantize = 1;
+    int wf_width = 4;               // node width of the wavefront traversal: 4 (64-byte quantised nodes), or 8 (128-byte; measured slower)
 
     // device scene
     DevBuf<float4> d_prim, d_primD, d_nodes, d_nodes4, d_lights;
     DevBuf<int> w_overflow;
-    DevBuf<uint4> d_nodes4q;
+    DevBuf<uint4> d_nodes4q, d_nodes8q;
     DevBuf<uint32_t> d_slot_of_index;
     DevBuf<float> d_spectra, d_cie;
     DevScene sc{};
@@ -361,6 +363,18 @@ int upload_geometry(crt_ctx *c, int mode)
         HIPCHK(c, hipMemcpy(c->d_nodes4q.p, c->bvh4q.nodes.data(), nq * sizeof(uint4), hipMemcpyHostToDevice));
         c->sc.nodes4q = c->d_nodes4q.p;
         for (int a = 0; a < 3; a++) { c->sc.qbase[a] = c->bvh4q.base[a]; c->sc.qscale[a] = c->bvh4q.scale[a]; }
+    }
+    c->bvh8q = Bvh8Q();
+    c->sc.nodes8q = nullptr;
+    c->sc.root8 = -1;
+    if (c->quantize && c->wf_width == 8 && c->bvh4q.ok) build_bvh8q(c->bvh, c->bvh8q);
+    if (c->bvh8q.ok) {
+        const size_t nq = c->bvh8q.nodes.size() / 4;
+        HIPCHK(c, c->d_nodes8q.alloc(nq));
+        HIPCHK(c, hipMemcpy(c->d_nodes8q.p, c->bvh8q.nodes.data(), nq * sizeof(uint4), hipMemcpyHostToDevice));
+        c->sc.nodes8q = c->d_nodes8q.p;
+        c->sc.root8 = c->bvh8q.root;
+        for (int a = 0; a < 3; a++) { c->sc.qbase[a] = c->bvh8q.base[a]; c->sc.qscale[a] = c->bvh8q.scale[a]; }
     }
     c->sc.nodes = c->d_nodes.p;
     c->sc.root = c->bvh.root;
@@ -864,7 +878,7 @@ void crt_destroy(crt_ctx *c)
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
 
     delete c->run;
-    c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_lights.release(); c->w_overflow.release();
+    c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_nodes8q.release(); c->d_lights.release(); c->w_overflow.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
@@ -1238,9 +1252,10 @@ int crt_accel_stats(crt_ctx *c, uint64_t out[8])
 {
     if (!c || !out) return CRT_EINVAL;
     const bool wide = c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2 && c->bvh4.n_inner > 0;
+    const bool wide8 = wide && c->bvh8q.ok;
     out[4] = wide ? (c->bvh4q.ok ? 16 : 32) : 32;      // bytes of node data per child box tested
-    out[5] = wide ? 4 : 2;                              // node width used by crt_trace
-    out[6] = wide ? c->bvh4.n_inner : c->bvh.n_inner;   // inner nodes of that tree
+    out[5] = wide8 ? 8 : wide ? 4 : 2;                  // node width used by crt_trace
+    out[6] = wide8 ? c->bvh8q.n_inner : wide ? c->bvh4.n_inner : c->bvh.n_inner;   // inner nodes of that tree
     out[7] = 0;
     out[0] = c->bvh.n_inner; out[1] = c->bvh.n_leaves; out[2] = c->bvh.max_depth;
     out[3] = (uint64_t)c->bvh.n_inner * 64u + (uint64_t)c->bvh4.n_inner * 128u + (uint64_t)c->prims.size() * 48u;
@@ -1255,6 +1270,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }
     if (!std::strcmp(name, "quantize")) { c->quantize = value ? 1 : 0; return CRT_OK; }   // takes effect at crt_build_accel
+    if (!std::strcmp(name, "wf_width")) { c->wf_width = value == 4 ? 4 : 8; return CRT_OK; }   // takes effect at crt_build_accel
     if (!std::strcmp(name, "wf_finish_at")) { c->wf_finish_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_flush_at")) { c->wf_flush_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_side_ppw")) { c->wf_side_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }

@@ -316,4 +316,95 @@ void quantize_bvh4(const Bvh4 &b4, Bvh4Q &out)
     out.ok = true;
 }
 
+
+namespace {
+struct Node8 { Child4 ch[8]; int n; };
+int32_t collapse8_rec(const Bvh &b2, int32_t ref2, std::vector<Node8> &nodes, uint32_t depth, uint32_t &max_depth)
+{
+    if (ref2 < 0) { max_depth = std::max(max_depth, depth); return ref2; }
+    Node8 nd;
+    nd.n = 2;
+    children_of(b2, ref2, nd.ch);
+    while (nd.n < 8) {                    // open the inner child with the largest surface
+        int best = -1; float ba = -1.0f;
+        for (int i = 0; i < nd.n; i++) if (nd.ch[i].ref >= 0) { float a = area_of(nd.ch[i]); if (a > ba) { ba = a; best = i; } }
+        if (best < 0) break;
+        Child4 two[2];
+        children_of(b2, nd.ch[best].ref, two);
+        nd.ch[best] = two[0];
+        nd.ch[nd.n++] = two[1];
+    }
+    const size_t me = nodes.size();
+    nodes.push_back(nd);
+    for (int i = 0; i < nd.n; i++) {
+        const int32_t r = collapse8_rec(b2, nd.ch[i].ref, nodes, depth + 1, max_depth);
+        nodes[me].ch[i].ref = r;
+    }
+    return (int32_t)me;
+}
+}  // namespace
+
+void build_bvh8q(const Bvh &b2, Bvh8Q &out)
+{
+    out = Bvh8Q();
+    if (b2.root < 0 || b2.n_inner == 0) return;
+    std::vector<Node8> nodes;
+    nodes.reserve(b2.n_inner / 3 + 16);
+    uint32_t max_depth = 0;
+    const int32_t root = collapse8_rec(b2, b2.root, nodes, 0, max_depth);
+    if (root < 0) return;
+    // scene bounds / quantisability (same rules as quantize_bvh4)
+    float glo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, ghi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (const Node8 &nd : nodes)
+        for (int i = 0; i < nd.n; i++)
+            for (int a = 0; a < 3; a++) {
+                const float l = nd.ch[i].lo[a], h = nd.ch[i].hi[a];
+                if (!(l > -1.0e30f) || !(h < 1.0e30f)) return;      // unbounded primitive: not quantisable
+                glo[a] = std::min(glo[a], l); ghi[a] = std::max(ghi[a], h);
+            }
+    for (int a = 0; a < 3; a++) {
+        const float ext = std::max(ghi[a] - glo[a], 1.0e-3f);
+        const float mag = std::max(std::fabs(glo[a]), std::fabs(ghi[a]));
+        if (mag > 16.0f * ext) return;                              // too far from the origin for the slack
+        out.base[a] = glo[a];
+        out.scale[a] = ext / 65533.0f;
+    }
+    // breadth-first numbering
+    std::vector<int32_t> order; order.reserve(nodes.size());        // order[new] = old
+    std::vector<int32_t> newid(nodes.size(), -1);
+    order.push_back(root); newid[root] = 0;
+    for (size_t head = 0; head < order.size(); head++) {
+        const Node8 &nd = nodes[order[head]];
+        for (int i = 0; i < nd.n; i++) {
+            const int32_t r = nd.ch[i].ref;
+            if (r >= 0 && newid[r] < 0) { newid[r] = (int32_t)order.size(); order.push_back(r); }
+        }
+    }
+    out.nodes.assign(order.size() * 32, 0u);
+    for (size_t k = 0; k < order.size(); k++) {
+        const Node8 &nd = nodes[order[k]];
+        uint16_t q[48];                                             // [plane 0..5][child 0..7]
+        int32_t refs[8];
+        for (int i = 0; i < 8; i++) {
+            const bool empty = i >= nd.n;
+            refs[i] = empty ? 0 : (nd.ch[i].ref >= 0 ? newid[nd.ch[i].ref] : nd.ch[i].ref);
+            for (int a = 0; a < 3; a++) {
+                if (empty) { q[8 * a + i] = 65535; q[24 + 8 * a + i] = 0; continue; }
+                const double l = ((double)nd.ch[i].lo[a] - out.base[a]) / out.scale[a];
+                const double h = ((double)nd.ch[i].hi[a] - out.base[a]) / out.scale[a];
+                const long ql = (long)std::floor(l) - 1, qh = (long)std::ceil(h) + 1;
+                q[8 * a + i] = (uint16_t)std::min<long>(std::max<long>(ql, 0), 65535);
+                q[24 + 8 * a + i] = (uint16_t)std::min<long>(std::max<long>(qh, 0), 65535);
+            }
+        }
+        uint32_t *o = &out.nodes[k * 32];
+        for (int d = 0; d < 24; d++) o[d] = (uint32_t)q[2 * d] | ((uint32_t)q[2 * d + 1] << 16);
+        std::memcpy(&o[24], refs, 32);
+    }
+    out.root = 0;
+    out.n_inner = (uint32_t)order.size();
+    out.max_depth = max_depth;
+    out.ok = true;
+}
+
 }  // namespace crt

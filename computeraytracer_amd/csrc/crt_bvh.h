@@ -52,4 +52,20 @@ struct Bvh4Q {
 };
 void quantize_bvh4(const Bvh4 &b4, Bvh4Q &out);
 
+// 8-wide quantised form, collapsed straight from the BVH2: 128 bytes per node = one L2 line, so a node
+// costs one memory request like a 64-byte one but a ray visits ~1/3 fewer of them (the traversal kernel
+// runs at the memory system's random-request rate, not at its bandwidth -- DESIGN.md 5.1).
+//   dwords  0.. 3  lo.x of children 0..7 (two 16-bit grid coordinates per dword, child 2k in the low half)
+//           4.. 7  lo.y     8..11  lo.z    12..15  hi.x    16..19  hi.y    20..23  hi.z
+//          24..31  child references (>= 0: 8-wide node index, < 0: ~(first_slot << 3 | count-1) as in the BVH2)
+// Same grid, slack and empty-slot convention as Bvh4Q; nodes are numbered breadth-first.
+struct Bvh8Q {
+    std::vector<uint32_t> nodes;   // 32 dwords per node
+    float base[3] = {0, 0, 0}, scale[3] = {1, 1, 1};
+    int32_t root = -1;
+    uint32_t n_inner = 0, max_depth = 0;
+    bool ok = false;
+};
+void build_bvh8q(const Bvh &b2, Bvh8Q &out);
+
 }  // namespace crt

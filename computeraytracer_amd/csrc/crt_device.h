@@ -34,12 +34,14 @@ struct DevScene {
     const float4 *nodes;
     const float4 *nodes4;       // 8 x float4 per 4-wide node (128 B)
     const uint4 *nodes4q;       // 4 x uint4 per quantised 4-wide node (64 B), or null
+    const uint4 *nodes8q;       // 8 x uint4 per quantised 8-wide node (128 B = one L2 line), or null
     const float *spectra;
     const float *cie;
     const float4 *lights;
     uint32_t nprim;
     int32_t root;
     int32_t root4;
+    int32_t root8;
     uint32_t n_nodes4;
     uint32_t nspectra;
     uint32_t nlight;

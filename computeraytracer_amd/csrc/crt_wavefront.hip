@@ -543,14 +543,15 @@ __device__ __forceinline__ void tri_test(const float4 A, const float4 B, const f
 // Traversal is "while-while": a bounded run of inner-node steps (lanes that reach a leaf wait,
 // cheaply), then one leaf step for every lane that has one -- so the expensive primitive tests
 // run with most lanes on.
-template <bool COUNT, bool QUANT>
+// QUANT: 0 = plain 4-wide nodes (128 B), 1 = quantised 4-wide (64 B), 2 = quantised 8-wide (128 B)
+template <bool COUNT, int QUANT>
 __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParams P, uint32_t it)
 {
     __shared__ int lds_stack[kWfStack * 64];
     WfCtl *ctl = P.ctl;
     // hot arrays as plain locals (keeps them in the global address space: global_load, not flat_load)
     const float4 *__restrict__ nodes = CRT_WF_BVH4 ? P.sc.nodes4 : P.sc.nodes;
-    const uint4 *__restrict__ nodesq = P.sc.nodes4q;
+    const uint4 *__restrict__ nodesq = QUANT == 2 ? P.sc.nodes8q : P.sc.nodes4q;
     const f3 qscale = f3{P.sc.qscale[0], P.sc.qscale[1], P.sc.qscale[2]}, qbase = f3{P.sc.qbase[0], P.sc.qbase[1], P.sc.qbase[2]};
     const float4 *__restrict__ prim = P.sc.prim;
     const float4 *__restrict__ primD = P.sc.primD;
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     const uint32_t *__restrict__ list2 = P.list[it & 1u][2];
     const uint32_t *__restrict__ list3 = P.list[it & 1u][3];
     const float hit_pad = P.sc.hit_pad;
-    const int root = CRT_WF_BVH4 ? P.sc.root4 : P.sc.root;
+    const int root = QUANT == 2 ? P.sc.root8 : CRT_WF_BVH4 ? P.sc.root4 : P.sc.root;
     int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
     const size_t ovl = P.overflow_lanes;
     const uint32_t nprim = P.sc.nprim;
@@ -713,7 +714,55 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                 }
             } else {
                 if (COUNT) { d_inner_it++; d_inner_act += (uint32_t)ni; }
-                if (inner) {
+                if (inner && QUANT == 2) {
+                    // one 128-byte node = one L2 line: 16-bit plane coordinates of 8 children, near / far plane
+                    // picked by the ray's signs; child 2k sits in the low half of dword k, child 2k+1 in the high half
+                    const uint4 *nq = nodesq + 8 * (size_t)node;
+                    const uint4 LX = nq[0], LY = nq[1], LZ = nq[2], HX = nq[3], HY = nq[4], HZ = nq[5], RA = nq[6], RB = nq[7];
+                    const bool gx = nx != 0, gy = ny != 0, gz = nz != 0;
+                    const uint4 NX = gx ? HX : LX, FX = gx ? LX : HX;
+                    const uint4 NY = gy ? HY : LY, FY = gy ? LY : HY;
+                    const uint4 NZ = gz ? HZ : LZ, FZ = gz ? LZ : HZ;
+                    float k0, k1, k2, k3, k4, k5, k6, k7;
+#define CRT_QBOX8(K, C, LOHI) { \
+                        const float tn_ = __builtin_fmaxf(__builtin_fmaxf(fma_((float)(LOHI(NX.C)), id.x, oid.x), fma_((float)(LOHI(NY.C)), id.y, oid.y)), \
+                                                          __builtin_fmaxf(fma_((float)(LOHI(NZ.C)), id.z, oid.z), t_min)); \
+                        const float tf_ = __builtin_fminf(__builtin_fminf(fma_((float)(LOHI(FX.C)), id.x, oid.x), fma_((float)(LOHI(FY.C)), id.y, oid.y)), \
+                                                          __builtin_fminf(fma_((float)(LOHI(FZ.C)), id.z, oid.z), t_max)); \
+                        K = (tn_ <= tf_ * 1.0000005f) ? tn_ : 3.0e38f; }
+#define CRT_LO16(v) ((v) & 0xFFFFu)
+#define CRT_HI16(v) ((v) >> 16)
+                    CRT_QBOX8(k0, x, CRT_LO16) CRT_QBOX8(k1, x, CRT_HI16) CRT_QBOX8(k2, y, CRT_LO16) CRT_QBOX8(k3, y, CRT_HI16)
+                    CRT_QBOX8(k4, z, CRT_LO16) CRT_QBOX8(k5, z, CRT_HI16) CRT_QBOX8(k6, w, CRT_LO16) CRT_QBOX8(k7, w, CRT_HI16)
+#undef CRT_QBOX8
+#undef CRT_LO16
+#undef CRT_HI16
+                    int r0 = (int)RA.x, r1 = (int)RA.y, r2 = (int)RA.z, r3 = (int)RA.w, r4 = (int)RB.x, r5 = (int)RB.y, r6 = (int)RB.z, r7 = (int)RB.w;
+                    if (COUNT) c_nodes += 8;
+                    // sort the eight (key, ref) pairs by entry distance: Batcher's 19 compare-exchanges
+#define CRT_CAS(ka, ra, kb, rb) { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; kb = sw_ ? ka : kb; ka = tk_; \
+                                  const int tr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = tr_; }
+                    CRT_CAS(k0, r0, k1, r1) CRT_CAS(k2, r2, k3, r3) CRT_CAS(k4, r4, k5, r5) CRT_CAS(k6, r6, k7, r7)
+                    CRT_CAS(k0, r0, k2, r2) CRT_CAS(k1, r1, k3, r3) CRT_CAS(k4, r4, k6, r6) CRT_CAS(k5, r5, k7, r7)
+                    CRT_CAS(k1, r1, k2, r2) CRT_CAS(k5, r5, k6, r6)
+                    CRT_CAS(k0, r0, k4, r4) CRT_CAS(k1, r1, k5, r5) CRT_CAS(k2, r2, k6, r6) CRT_CAS(k3, r3, k7, r7)
+                    CRT_CAS(k2, r2, k4, r4) CRT_CAS(k3, r3, k5, r5)
+                    CRT_CAS(k1, r1, k2, r2) CRT_CAS(k3, r3, k4, r4) CRT_CAS(k5, r5, k6, r6)
+#undef CRT_CAS
+#define CRT_PUSH(K, R) if (K < 3.0e38f) { if (sp < kWfStack) stk[sp * 64] = R; else ovf[(size_t)(sp - kWfStack) * ovl] = R; sp++; }
+                    if (k0 < 3.0e38f) {
+                        // descend into the nearest; the others wait on the stack, farthest pushed first
+                        CRT_PUSH(k7, r7) CRT_PUSH(k6, r6) CRT_PUSH(k5, r5) CRT_PUSH(k4, r4) CRT_PUSH(k3, r3) CRT_PUSH(k2, r2) CRT_PUSH(k1, r1)
+                        node = r0;
+                    } else if (sp > 0) {
+                        sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
+                    } else {
+                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                        active = false;
+                    }
+#undef CRT_PUSH
+                } else if (inner) {
 #if CRT_WF_BVH4
                   float k0, k1, k2, k3;
                   int r0, r1, r2, r3;
@@ -955,9 +1004,16 @@ hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s)
 {
     const dim3 g(trace_blocks), b(64);
-    const bool q = CRT_WF_BVH4 && P.sc.nodes4q != nullptr;
-    if (P.count) { if (q) hipLaunchKernelGGL((k_wf_trace<true, true>), g, b, 0, s, P, it); else hipLaunchKernelGGL((k_wf_trace<true, false>), g, b, 0, s, P, it); }
-    else { if (q) hipLaunchKernelGGL((k_wf_trace<false, true>), g, b, 0, s, P, it); else hipLaunchKernelGGL((k_wf_trace<false, false>), g, b, 0, s, P, it); }
+    const int q = !CRT_WF_BVH4 ? 0 : P.sc.nodes8q != nullptr ? 2 : P.sc.nodes4q != nullptr ? 1 : 0;
+    if (P.count) {
+        if (q == 2) hipLaunchKernelGGL((k_wf_trace<true, 2>), g, b, 0, s, P, it);
+        else if (q == 1) hipLaunchKernelGGL((k_wf_trace<true, 1>), g, b, 0, s, P, it);
+        else hipLaunchKernelGGL((k_wf_trace<true, 0>), g, b, 0, s, P, it);
+    } else {
+        if (q == 2) hipLaunchKernelGGL((k_wf_trace<false, 2>), g, b, 0, s, P, it);
+        else if (q == 1) hipLaunchKernelGGL((k_wf_trace<false, 1>), g, b, 0, s, P, it);
+        else hipLaunchKernelGGL((k_wf_trace<false, 0>), g, b, 0, s, P, it);
+    }
     return hipGetLastError();
 }
 

@@ -165,6 +165,7 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
  * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
  * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "wf_pipes": half-pools
  * on separate streams; "wf_defer": 0 = every crt_trace call runs its paths to the end;
+ * "quantize", "wf_width" (4 | 8: node width of the wavefront traversal; at crt_build_accel);
  * "time_kernels".  Setting an option first finishes what is in flight. */
 int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);
 

@@ -281,19 +281,20 @@ def test_checkpoint_resume(renderer):
 
 
 def test_every_pipeline_form_gives_the_same_image(renderer, orc):
-    """Wavefront pipeline with quantised 4-wide nodes (default), with plain 4-wide nodes, and the
-    single-kernel form on the BVH2: one image, bit for bit (and equal to the oracle on a crop)."""
+    """Wavefront pipeline with quantised 4-wide nodes (default), with quantised 8-wide nodes, with plain
+    4-wide nodes, and the single-kernel form on the BVH2: one image, bit for bit (and equal to the oracle
+    on a crop)."""
     ps = _mixed_scene(640, 360)
     imgs = []
     try:
-        for pipeline, quant in [(1, 1), (1, 0), (0, 1)]:
-            renderer.set_option("pipeline", pipeline).set_option("quantize", quant)
+        for pipeline, quant, width in [(1, 1, 4), (1, 1, 8), (1, 0, 4), (0, 1, 4)]:
+            renderer.set_option("pipeline", pipeline).set_option("quantize", quant).set_option("wf_width", width)
             acc, rgba = render(renderer, ps, 5)
             imgs.append((acc, rgba))
             st = renderer.accel_stats()
-            assert st["width"] == (4 if pipeline else 2) and st["bytes_per_box"] == (16 if (pipeline and quant) else 32)
+            assert st["width"] == (width if pipeline else 2) and st["bytes_per_box"] == (16 if (pipeline and quant) else 32)
     finally:
-        renderer.set_option("pipeline", 1).set_option("quantize", 1)
+        renderer.set_option("pipeline", 1).set_option("quantize", 1).set_option("wf_width", 4)
     for acc, rgba in imgs[1:]:
         assert np.array_equal(bits(acc), bits(imgs[0][0])) and np.array_equal(rgba, imgs[0][1])
     rect = (300, 170, 340, 200)
