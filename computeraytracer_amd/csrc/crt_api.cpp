@@ -136,13 +136,15 @@ struct crt_ctx {
     int wf_pipes = 2;
     int wf_defer = 1;               // 1: a batch ends parked, its last paths finish under the next batch (or at crt_sync)
     int wf_tail_walk = 1;           // shade walks the ray lists once few paths are left
+    int wf_park_its = 4;            // a batch parks when its queue holds less than this many iterations' worth
+    int wf_chunk = 2;               // iterations enqueued per status readback (the host's decisions lag by two chunks)
     WfRun *run = nullptr;           // pipeline state between calls
     uint32_t wf_finish_at = 32768;  // paths of the previous batch left (per pipe) at which they move to the side pool; 0 = never
     uint32_t wf_flush_at = 4096;    // the same for the LAST batch at crt_sync (nothing to hide its tail under); 0 = never
     uint32_t wf_side_ppw = 64, wf_flush_ppw = 4;   // k_wf_finish: paths per wave, under the next batch / at crt_sync
     DevBuf<WfCtl> w_ctl[kMaxPipes];
     DevBuf<WfWorkQ> w_wq;
-    WfWorkQ *h_wq[2] = {nullptr, nullptr};                 // pinned
+    WfWorkQ *h_wq[kMaxPipes][2] = {};                      // pinned: each pipe's snapshots of the two work queues
     WfCtl *h_ctl[kMaxPipes][2] = {};                       // pinned, double-buffered status readbacks
     hipEvent_t ev_ctl[kMaxPipes][2] = {};
     hipStream_t pipe_stream[kMaxPipes] = {};               // the pipes' own streams (the context's stream only forks and resolves)
@@ -397,8 +399,8 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
     for (int b = 0; b < 2; b++)
         if (c->w_staging[b].n < staging_elems) HIPCHK(c, c->w_staging[b].alloc(staging_elems));
     if (!c->w_wq.p) {
-        HIPCHK(c, c->w_wq.alloc(1));
-        HIPCHK(c, hipMemset(c->w_wq.p, 0, sizeof(WfWorkQ)));
+        HIPCHK(c, c->w_wq.alloc(2));
+        HIPCHK(c, hipMemset(c->w_wq.p, 0, 2 * sizeof(WfWorkQ)));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
             HIPCHK(c, c->w_ctl[p].alloc(1));
@@ -410,7 +412,8 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[p], hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_evict[p], hipEventDisableTiming));
         }
-        for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[b], sizeof(WfWorkQ), hipHostMallocDefault));
+        for (int p = 0; p < crt_ctx::kMaxPipes; p++)
+            for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[p][b], 2 * sizeof(WfWorkQ), hipHostMallocDefault));
     }
     if (c->num_cu == 0) {
         hipDeviceProp_t prop;
@@ -428,12 +431,13 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
 struct WfPipe {
     WfParams W{};
     hipStream_t stream = nullptr;
-    uint32_t it = 0, chunk = 4, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
+    uint32_t it = 0, chunk = 2, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
     uint32_t it_fresh = 0;          // iterations >= it_fresh belong to the batch whose work queue is loaded
     int cur = 0;                    // status buffer of the chunk that is outstanding between driver passes
     bool done = false;              // no more chunks are enqueued for this pipe (drained, evicted or parked)
     bool fresh = false;             // a status of the loaded batch has been read
     unsigned long long rays = 0, old = 0;   // from the last status read: rays listed / paths of the previous batch alive
+    bool prev_dry = true;           // that status saw the previous batch's queue empty
     uint32_t evict_next = 0;        // evict_mask for the first shade launch of the next chunk
 };
 
@@ -450,11 +454,14 @@ struct WfBatch { bool open = false; uint32_t n = 0, last_sample = 0, parity = 0;
 struct WfRun {
     bool live = false;              // pipes are forked; every pipe has one outstanding chunk in status buffer [cur]
     int K = 0;
-    uint32_t P = 0, Pp = 0, list_cap = 0, trace_blocks = 0, work_per_shard = 0;
-    unsigned long long work_total = 0;
+    uint32_t P = 0, Pp = 0, list_cap = 0, trace_blocks = 0;
+    uint32_t seg_wps[2] = {0, 0};           // per batch parity: work items per shard / in total
+    unsigned long long seg_total[2] = {0, 0};
     WfPipe pipes[crt_ctx::kMaxPipes];
     WfBatch cur, prev;
-    bool work_left = false;
+    bool cur_left = false, prev_left = false;   // the loaded batch's / the previous batch's queue still holds work
+    bool work_left = false;                      // either of them
+    unsigned long long left_its = ~0ull;         // iterations until the loaded batch's queue is dry (estimate)
     uint32_t rate_it = 0;                   // pipe 0's iteration and the work consumed at its last status
     unsigned long long rate_consumed = 0;
 };
@@ -539,7 +546,7 @@ int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
     }
     pp.it_end[buf] = pp.it;
     HIPCHK(c, hipMemcpyAsync(c->h_ctl[p][buf], pp.W.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, pp.stream));
-    if (p == 0) HIPCHK(c, hipMemcpyAsync(c->h_wq[buf], c->w_wq.p, sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_wq[p][buf], c->w_wq.p, 2 * sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
     HIPCHK(c, hipEventRecord(c->ev_ctl[p][buf], pp.stream));
     return CRT_OK;
 }
@@ -582,27 +589,44 @@ int wf_drive(crt_ctx *c, bool to_end)
             if (pp.done) continue;
             HIPCHK(c, hipEventSynchronize(c->ev_ctl[p][pp.cur]));
             if (pp.it_end[pp.cur] <= pp.it_fresh) { pp.cur ^= 1; continue; }      // a status from before this batch began
-            if (p == 0) {
+            auto seg_left = [&](uint32_t par, unsigned long long &consumed) {
                 bool left = false;
+                consumed = 0;
                 for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-                    const unsigned long long lo = (unsigned long long)sidx * r.work_per_shard;
-                    const unsigned long long size = lo < r.work_total ? std::min<unsigned long long>(r.work_per_shard, r.work_total - lo) : 0;
-                    if (c->h_wq[pp.cur]->work[sidx].cur < size) left = true;
+                    const unsigned long long lo = (unsigned long long)sidx * r.seg_wps[par];
+                    const unsigned long long size = lo < r.seg_total[par] ? std::min<unsigned long long>(r.seg_wps[par], r.seg_total[par] - lo) : 0;
+                    const unsigned long long cur = c->h_wq[p][pp.cur][par].work[sidx].cur;
+                    if (cur < size) left = true;
+                    consumed += std::min(cur, size);
                 }
-                r.work_left = left;                              // monotone within a batch: once false it stays false
-                // Chunks shrink as the queue runs dry: what is enqueued ahead of the status that shows it empty
-                // runs on a nearly empty pool, and the host needs only ~20 us per launch to keep up.
+                return left;
+            };
+            // (each pipe judges the previous batch's queue by its OWN snapshot: its survivor count only means
+            // something once no more of that batch's paths can start in THIS pipe)
+            if (!pp.prev_dry) { unsigned long long d_ = 0; pp.prev_dry = !r.prev.open || !seg_left(r.prev.parity, d_); }
+            if (p == 0) {
                 unsigned long long consumed = 0;
-                for (uint32_t sidx = 0; sidx < kWfShards; sidx++) consumed += std::min<unsigned long long>(c->h_wq[pp.cur]->work[sidx].cur, r.work_per_shard);
-                consumed = std::min(consumed, r.work_total);
+                r.cur_left = seg_left(r.cur.parity, consumed);   // monotone within a batch: once false it stays false
+                r.prev_left = !pp.prev_dry;
+                r.work_left = r.cur_left || r.prev_left;
+                // How many iterations until the loaded batch's queue is dry.  Chunks shrink as that comes close when
+                // no further batch can take over (to_end): what is enqueued ahead of the status that shows the queue
+                // empty runs on a nearly empty pool, and the host needs only ~20 us per launch to keep up.
                 const uint32_t its = pp.it_end[pp.cur] - r.rate_it;
-                if (its > 0 && consumed > r.rate_consumed) {
+                if (!r.cur_left) r.left_its = 0;
+                else if (its > 0 && consumed > r.rate_consumed) {
                     const unsigned long long per_it = (consumed - r.rate_consumed) / its;
-                    const unsigned long long left_its = (r.work_total - consumed) / std::max<unsigned long long>(per_it, 1);
-                    const uint32_t chunk = left_its >= 16 ? 4u : left_its >= 6 ? 2u : 1u;
+                    r.left_its = (r.seg_total[r.cur.parity] - consumed) / std::max<unsigned long long>(per_it, 1);
+                }
+                if (to_end || r.prev.open) {
+                    const uint32_t chunk = r.left_its >= 6 ? (uint32_t)c->wf_chunk : 1u;
                     for (int q = 0; q < K; q++) r.pipes[q].chunk = chunk;
                 }
                 r.rate_it = pp.it_end[pp.cur]; r.rate_consumed = consumed;
+                for (int q = 0; q < K; q++) {                     // which queues the next chunks re-arm from
+                    r.pipes[q].W.seg_first = r.prev_left ? r.prev.parity : r.cur.parity;
+                    r.pipes[q].W.seg_second = r.prev_left ? r.cur.parity : 2u;
+                }
             }
             const WfCtl *hc = c->h_ctl[p][pp.cur];
             unsigned long long rays = 0, old = 0;
@@ -622,9 +646,10 @@ int wf_drive(crt_ctx *c, bool to_end)
             // may be left simply keeps going (its dead slots re-arm as soon as they see work)
             if (!r.work_left && rays == 0) { pp.done = true; pp.old = 0; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
             if (!to_end) {
-                // Park: the queue is empty and the batch before this one is resolved.  The chunk already
-                // enqueued ahead keeps the GPU busy until the next batch's work arrives.
-                if (!r.work_left && !r.prev.open) { pp.done = true; pp.cur ^= 1; active--; continue; }
+                // Park: the batch before this one is resolved and this one's queue is nearly dry -- NEARLY, so that the
+                // next call can publish its queue while this one still holds work and the chunk already enqueued
+                // ahead keeps the GPU busy: the pool never runs dry between batches.
+                if (!r.prev.open && r.left_its < (unsigned long long)c->wf_park_its) { pp.done = true; pp.cur ^= 1; active--; continue; }
             } else if (!r.work_left && !cur_evicting) {
                 if (rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull) && c->wf_tail_walk) {
                     // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
@@ -644,7 +669,7 @@ int wf_drive(crt_ctx *c, bool to_end)
             for (int p = 0; p < K; p++) {
                 const WfPipe &pp = r.pipes[p];
                 if (pp.done) continue;                           // (a drained pipe holds no path at all)
-                all_fresh = all_fresh && pp.fresh; old += pp.old; old_max = std::max(old_max, pp.old);
+                all_fresh = all_fresh && pp.fresh && pp.prev_dry; old += pp.old; old_max = std::max(old_max, pp.old);
             }
             if (all_fresh && old == 0) { int rc = wf_resolve_batch(c, r.prev); if (rc) return rc; }
             else if (all_fresh && old_max <= kWfSideCap && old <= evict_at * (unsigned)K) {
@@ -748,17 +773,19 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     }
     int rc = wf_ensure(c, (size_t)g.P + side_slots, staging_elems, g.list_per_pipe * (size_t)g.K);
     if (rc) return rc;
-    r.work_total = g.work_total; r.work_per_shard = g.work_per_shard;
-    r.work_left = true;
     r.rate_consumed = 0;
+    r.left_its = ~0ull;
     if (!r.live) {
         r.K = g.K; r.P = g.P; r.Pp = g.Pp; r.list_cap = g.list_cap;
         r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
         r.prev = WfBatch();
         r.cur = WfBatch{true, n, c->sample + n, 0u};
         r.rate_it = 0;
+        r.seg_total[0] = g.work_total; r.seg_wps[0] = g.work_per_shard;
+        r.cur_left = r.work_left = true; r.prev_left = false;
         for (int p = 0; p < r.K; p++) {
             r.pipes[p] = WfPipe();
+            r.pipes[p].chunk = (uint32_t)c->wf_chunk;
             WfParams &W = r.pipes[p].W;
             W.sc = c->sc;
             W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
@@ -774,9 +801,12 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.slot_base = side_slots + g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
             W.P = g.Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
             W.band = c->band; W.stride = c->stride; W.phase = c->phase;
-            W.tiles_x = g.tiles_x; W.tiles_y = g.tiles_y; W.npix_padded = g.npix_padded; W.work_total = g.work_total;
-            W.work_per_shard = g.work_per_shard; W.list_cap = g.list_cap;
-            W.first_sample = c->sample + 1; W.n_samples = n;
+            W.tiles_x = g.tiles_x; W.tiles_y = g.tiles_y; W.npix_padded = g.npix_padded;
+            W.list_cap = g.list_cap;
+            W.seg[0] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
+            W.seg[1] = WfSeg{0, 64, 0};
+            W.seg_first = 0; W.seg_second = 2;
+            W.n_samples = n;
             W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
             W.count = c->counting ? 1u : 0u;
             W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
@@ -810,23 +840,27 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         // while this batch's work flows into the slots that are free.
         r.prev = r.cur;
         r.cur = WfBatch{true, n, c->sample + n, r.prev.parity ^ 1u};
+        const uint32_t np = r.cur.parity;
+        r.seg_total[np] = g.work_total; r.seg_wps[np] = g.work_per_shard;
+        r.prev_left = r.cur_left;                    // (the parked batch's queue may still hold work)
+        r.cur_left = r.work_left = true;
         for (int p = 0; p < r.K; p++) {
             WfPipe &pp = r.pipes[p];
-            pp.W.first_sample = c->sample + 1; pp.W.n_samples = n;
-            pp.W.work_total = g.work_total; pp.W.work_per_shard = g.work_per_shard;
-            pp.W.batch_parity = r.cur.parity; pp.W.keep_pool = 1;
+            pp.W.seg[np] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
+            pp.W.n_samples = n;
+            pp.W.batch_parity = np; pp.W.keep_pool = 1;
+            pp.W.seg_first = r.prev_left ? r.prev.parity : np;
+            pp.W.seg_second = r.prev_left ? np : 2u;
             pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
             pp.it_fresh = pp.it;
-            pp.fresh = false; pp.old = 0; pp.evict_next = 0; pp.chunk = 4;
+            pp.fresh = false; pp.old = 0; pp.evict_next = 0; pp.chunk = (uint32_t)c->wf_chunk;
+            pp.prev_dry = !r.prev_left;
         }
         r.rate_it = r.pipes[0].it;
-        // Every kernel enqueued so far still belongs to the parked batch (old parameters, an empty
-        // queue): the queue is refilled only after all of them, and nobody continues before it is.
-        for (int p = 0; p < r.K; p++) {
-            HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
-        }
-        for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->stream));   // (one block each: queue + side counters)
+        // This batch's queue and side counters are reset on the control stream.  Nothing in flight looks at
+        // them: every kernel enqueued so far was told there is no second queue, and the batch that used this
+        // parity before is resolved.  The pipes only wait for the reset, not for each other.
+        for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->stream));   // (one block each)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
     }
@@ -894,7 +928,8 @@ void crt_destroy(crt_ctx *c)
         if (c->ev_join[p]) (void)hipEventDestroy(c->ev_join[p]);
         if (c->ev_evict[p]) (void)hipEventDestroy(c->ev_evict[p]);
     }
-    for (int b = 0; b < 2; b++) if (c->h_wq[b]) (void)hipHostFree(c->h_wq[b]);
+    for (int p = 0; p < crt_ctx::kMaxPipes; p++)
+        for (int b = 0; b < 2; b++) if (c->h_wq[p][b]) (void)hipHostFree(c->h_wq[p][b]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
 
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
@@ -1275,6 +1310,8 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_flush_at")) { c->wf_flush_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_side_ppw")) { c->wf_side_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_flush_ppw")) { c->wf_flush_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_chunk")) { c->wf_chunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_park_its")) { c->wf_park_its = (int)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_tail_walk")) { c->wf_tail_walk = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }

@@ -103,10 +103,18 @@ struct WfCtl {                       // device control block, one per context
     uint32_t side_count[2];          // paths moved to the side pool, per batch parity
 };
 // The work queue is shared by the pipes of a context (two half-pools run on two streams so that
-// one half's streaming shade pass overlaps the other half's latency-bound traversal).
+// one half's streaming shade pass overlaps the other half's latency-bound traversal).  There are two
+// of them, one per batch parity: the next batch's work is published while the current batch's queue
+// still holds a few iterations' worth, so the pool never runs dry between batches.
 struct WfWorkQ {
     WfWork work[kWfShards];
     uint32_t work_done, pad_[31];    // set once every work shard is exhausted (saves the scans)
+};
+// One batch's share of the parameters (indexed by batch parity like the queues and the staging buffers).
+struct WfSeg {
+    unsigned long long work_total;   // n_samples * npix_padded
+    uint32_t work_per_shard;         // work items per shard (multiple of 64)
+    uint32_t first_sample;
 };
 
 struct WfParams {
@@ -122,20 +130,20 @@ struct WfParams {
     uint32_t side_base[2];           // first side-pool slot of this pipe, per batch parity
     uint32_t evict_mask;             // k_wf_shade: bit b = move the alive paths of batch parity b to the side pool first
     WfCtl *ctl;
-    WfWorkQ *wq;
+    WfWorkQ *wq;                     // [2], by batch parity
+    WfSeg seg[2];
+    uint32_t seg_first, seg_second;  // parities of the queues dead slots re-arm from, in this order (second: 2 = none)
     uint32_t slot_base;              // this pipe's slots are [slot_base, slot_base + P)
-    uint32_t reset_wq;               // k_wf_init also resets the shared work queue
+    uint32_t reset_wq;               // k_wf_init also resets the work queue of batch_parity
     uint32_t P;                      // slots of this pipe
     uint32_t x0, y0, tw, th;         // tile rectangle (local buffer is tw x th)
     uint32_t band, stride, phase;    // row interleave: global y = y0 + (ly/band)*band*stride + phase*band + ly%band
     uint32_t tiles_x, tiles_y;
     uint32_t npix_padded;            // tiles_x*tiles_y*64: work item = sample_off * npix_padded + tile*64 + lane
-    unsigned long long work_total;   // n_samples * npix_padded
-    uint32_t work_per_shard;         // work items per shard (multiple of 64)
     uint32_t list_cap;               // list entries per shard
     uint32_t tail_bound;             // 0: one shade thread per slot; >0: tail mode, threads walk the previous
                                      //    iteration's ray lists (<= tail_bound entries per shard and list)
-    uint32_t first_sample, n_samples;
+    uint32_t n_samples;              // k_wf_resolve: samples of the batch to resolve
     float4 *accum;
     uchar4 *rgba;
     uint32_t count;                  // 1: maintain ctl->counters

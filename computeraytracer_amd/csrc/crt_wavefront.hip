@@ -308,28 +308,41 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         const bool want0 = in_pool && !alive;
         bool want = want0;
         const uint32_t lane = lane_id();
-        const bool all_done = __hip_atomic_load(&P.wq->work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        for (int attempt = 0; attempt < 3 && !all_done; attempt++) {
+        // up to two queues: the older batch's until it is dry, then the next batch's (published early)
+        uint32_t sg = P.seg_first;
+        int tries = 0;
+        bool dry = __hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        for (int attempt = 0; attempt < 6; attempt++) {
+            if (dry) {
+                if (sg == P.seg_second || P.seg_second > 1u) break;
+                sg = P.seg_second; tries = 0;
+                dry = __hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (dry) break;
+            }
             const unsigned long long m = __ballot(want);
-            if (!m) break;
+            if (!m || tries >= 3) break;
+            WfWorkQ *wq = P.wq + sg;
+            const uint32_t wps = P.seg[sg].work_per_shard;
+            const unsigned long long wtot = P.seg[sg].work_total;
             const uint32_t sh_lane = lane % kWfShards;
-            const unsigned long long lo = (unsigned long long)sh_lane * P.work_per_shard;
-            const unsigned long long hi = min(lo + (unsigned long long)P.work_per_shard, P.work_total);
+            const unsigned long long lo = (unsigned long long)sh_lane * wps;
+            const unsigned long long hi = min(lo + (unsigned long long)wps, wtot);
             const uint32_t size_l = hi > lo ? (uint32_t)(hi - lo) : 0u;
             uint32_t s_pick = my_shard;
-            if (attempt == 0) {
+            if (tries++ == 0) {
                 // one uniform load of the own cursor: skip the atomic when this shard is already dry
-                const unsigned long long lo0 = (unsigned long long)my_shard * P.work_per_shard;
-                const unsigned long long hi0 = min(lo0 + (unsigned long long)P.work_per_shard, P.work_total);
-                const uint32_t cur0 = __hip_atomic_load(&P.wq->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long lo0 = (unsigned long long)my_shard * wps;
+                const unsigned long long hi0 = min(lo0 + (unsigned long long)wps, wtot);
+                const uint32_t cur0 = __hip_atomic_load(&wq->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (hi0 <= lo0 || cur0 >= (uint32_t)(hi0 - lo0)) continue;
             } else {
                 // own shard ran dry: look at every cursor at once (lane i loads shard i) and move on
-                const uint32_t cur_l = __hip_atomic_load(&P.wq->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cur_l = __hip_atomic_load(&wq->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long avail = __ballot(cur_l < size_l);
                 if (!avail) {                                        // every shard is exhausted
-                    if (lane == 0) __hip_atomic_store(&P.wq->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                    if (lane == 0) __hip_atomic_store(&wq->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dry = true;
+                    continue;
                 }
                 const uint32_t rot = my_shard & 63u;
                 const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
@@ -337,20 +350,20 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             }
             const uint32_t n = (uint32_t)__popcll(m);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&P.wq->work[s_pick].cur, n);
+            if (lane == 0) base = atomicAdd(&wq->work[s_pick].cur, n);
             base = __shfl(base, 0, 64);
             const uint32_t size_s = __shfl(size_l, (int)s_pick, 64);
             const uint32_t got = base < size_s ? min(n, size_s - base) : 0u;
             const uint32_t my = prefix_popc(m, lane);
             if (want && my < got) {
                 want = false;
-                const unsigned long long w = (unsigned long long)s_pick * P.work_per_shard + base + my;
+                const unsigned long long w = (unsigned long long)s_pick * wps + base + my;
                 const uint32_t sample_off = (uint32_t)(w / P.npix_padded), pp = (uint32_t)(w % P.npix_padded);
                 const uint32_t tile = pp >> 6, l = pp & 63u;
                 const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
                 R.flags = 0;
                 if (lx < P.tw && ly < P.th) {
-                    const uint32_t px = P.x0 + lx, sample = P.first_sample + sample_off;
+                    const uint32_t px = P.x0 + lx, sample = P.seg[sg].first_sample + sample_off;
                     const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
                     R.rng = Rng{py, px * 100u, sample, tea(px, py * 100u)};                  // :98
                     float jx = rnd(R.rng);
@@ -366,7 +379,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                     R.beta = f4{1, 1, 1, 1}; R.radiance = f4{0, 0, 0, 0};
                     R.last_pdf = 1.0f; R.etaScale = 1.0f; R.exclude = 0xFFFFFFFFu;
                     R.work = (uint32_t)w;
-                    R.flags = kWfAlive | (lambda << kWfLambdaShift) | (P.batch_parity << kWfBatchShift);
+                    R.flags = kWfAlive | (lambda << kWfLambdaShift) | (sg << kWfBatchShift);
                     alive = true;
                     emit_ext = true;
                     ext_primary = true;
@@ -979,8 +992,8 @@ __global__ void k_wf_init(const WfParams P)
             for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
         if (i == 0) { c->side_count[P.batch_parity] = 0; if (!P.keep_pool) c->side_count[P.batch_parity ^ 1u] = 0; }
         if (P.reset_wq) {
-            P.wq->work[i].cur = 0;
-            if (i == 0) P.wq->work_done = 0;
+            P.wq[P.batch_parity].work[i].cur = 0;
+            if (i == 0) P.wq[P.batch_parity].work_done = 0;
         }
     }
 }
