@@ -108,8 +108,8 @@ int crt_reset(crt_ctx *ctx);
  * Samples are accumulated into alt_color_buffer in order; the rgba8
  * framebuffer holds the tone-mapped average after the last one.
  * Asynchronous, and (option "wf_defer", default 1) PIPELINED across calls: a call
- * returns once its samples' work queue is empty, while its last, longest paths are
- * still in flight; they finish under the next crt_trace call, or in crt_sync.  So:
+ * returns once its samples' work queue is nearly empty; the rest of its work and its
+ * last, longest paths finish under the next crt_trace call, or in crt_sync.  So:
  *   - after crt_sync (or any crt_read_*, crt_counters, crt_last_*_ms) the buffers
  *     hold every sample requested so far;
  *   - in between, buffers bound with crt_bind_output hold, in stream order, the
@@ -165,6 +165,8 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
  * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
  * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "wf_pipes": half-pools
  * on separate streams; "wf_defer": 0 = every crt_trace call runs its paths to the end;
+ * "wf_chunk" (iterations enqueued per status readback), "wf_park_its", "wf_finish_at",
+ * "wf_flush_at", "wf_side_ppw", "wf_flush_ppw", "wf_tail_walk": pipeline tuning;
  * "quantize", "wf_width" (4 | 8: node width of the wavefront traversal; at crt_build_accel);
  * "time_kernels".  Setting an option first finishes what is in flight. */
 int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);
