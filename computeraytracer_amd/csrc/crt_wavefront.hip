@@ -33,7 +33,7 @@ namespace crt {
 #define CRT_WF_STACK 32
 #endif
 #ifndef CRT_WF_REFILL
-#define CRT_WF_REFILL 16
+#define CRT_WF_REFILL 24
 #endif
 #ifndef CRT_WF_INNER_RUN
 #define CRT_WF_INNER_RUN 6
@@ -45,7 +45,7 @@ namespace crt {
 #define CRT_WF_BVH4 1
 #endif
 #ifndef CRT_WF_LEAF_AT
-#define CRT_WF_LEAF_AT 24
+#define CRT_WF_LEAF_AT 32
 #endif
 #ifndef CRT_WF_SHADE_BLOCK
 #define CRT_WF_SHADE_BLOCK 256

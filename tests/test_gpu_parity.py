@@ -383,6 +383,55 @@ def test_batches_pipelined_across_calls(renderer, orc):
         renderer.set_option("wf_defer", 1)
 
 
+def test_pipeline_state_machine_random_walk(renderer, orc):
+    """Seeded random sequences of crt_trace calls of changing size, with syncs / reads in between or not, over
+    random pipeline settings (pool size, pipes, chunk size, park threshold, eviction thresholds, tiles): after
+    each sequence the frame is the oracle's, bit for bit.  (Two batches in flight, two work queues, side pools,
+    eviction under the next batch and the flush at sync all have to agree for that.)"""
+    from computeraytracer_amd import cornell
+    W = H = 448
+    ps = cornell(W, H)
+    sc = orc.Scene.from_packed(ps)
+    full = {}
+    rng = np.random.default_rng(20260104)
+    renderer.upload(ps).build_accel("bvh2")
+    try:
+        for epoch in range(8):
+            opts = {"wf_pool": int(rng.choice([0, 1 << 18, 1 << 19])), "wf_pipes": int(rng.choice([1, 2])),
+                    "wf_chunk": int(rng.choice([1, 2, 4])), "wf_park_its": int(rng.choice([0, 4, 1000])),
+                    "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
+                    "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0]))}
+            for k, v in opts.items():
+                renderer.set_option(k, v)
+            rect = None
+            if rng.random() < 0.4:
+                x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
+                rect = (x0, y0, int(rng.integers(x0 + 40, W + 1)), int(rng.integers(y0 + 40, H + 1)))
+                renderer.set_tile(*rect)
+            else:
+                renderer.set_tile(0, 0, W, H)
+            total = 0
+            for _ in range(int(rng.integers(2, 7))):
+                n = int(rng.choice([1, 2, 2, 3, 5]))
+                renderer.frame(n)
+                total += n
+                what = rng.random()
+                if what < 0.2:
+                    renderer.sync()
+                elif what < 0.3:
+                    renderer.read_rgba8()
+            renderer.sync()
+            if total not in full:
+                full[total] = sc.render(total)[:2]
+            print(epoch, opts, rect, total)          # (shown by pytest if the comparison fails)
+            assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *full[total], rect=rect)
+            assert renderer.sample == total
+    finally:
+        for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 2, "wf_park_its": 4, "wf_finish_at": 32768,
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1}.items():
+            renderer.set_option(k, v)
+
+
 def test_one_sample_per_pixel_and_tiny_tiles(renderer, orc):
     """Pool larger than the work (1 spp on a small tile) and a 1x1 tile."""
     from computeraytracer_amd import cornell
