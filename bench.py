@@ -192,8 +192,10 @@ def main():
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S2 {args.scene}: {ntri} triangles + cornell walls/light, {W}x{H}, "
-                                   f"{args.spp} spp per step (BASELINE config 3)" if args.scene == "atrium250k" else
+            "config": {"workload": (f"S2 {args.scene}: {ntri} triangles + cornell walls/light, {W}x{H}, {args.spp} spp per step"
+                                    + (" (BASELINE config 3)" if (W, H, args.spp) == (1920, 1080, 64) else
+                                       " (BASELINE config 4)" if (W, H, args.spp) == (3840, 2160, 256) else ""))
+                                   if args.scene == "atrium250k" else
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
                        "partition": (f"rows dealt to {world} GPUs in bands of {args.band}" if world > 1 and args.band else f"{world} horizontal strip(s)")
                                     + ", scene replicated, all_gather of the rgba8 strips per step",
