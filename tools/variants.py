@@ -6,7 +6,7 @@ import sys, time; sys.path.insert(0,'.')
 from computeraytracer_amd import Renderer, scenes_synth
 ps = scenes_synth.atrium250k(1920,1080); r = Renderer(0); r.upload(ps).build_accel('bvh2')
 out = []
-for wpc in (14, 18):
+for wpc in (14,):
     r.set_option('wf_waves_per_cu', wpc)
     best = 1e9
     for _ in range(2):
@@ -17,7 +17,7 @@ for wpc in (14, 18):
 print(' | '.join(out))
 '''
 libs = [None] + sorted(glob.glob('tune_*.so'))
-for rnd in range(2):
+for rnd in range(4):
     for lib in libs:
         env = dict(os.environ)
         if lib: env['CRT_LIB'] = os.path.abspath(lib)
