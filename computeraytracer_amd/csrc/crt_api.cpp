@@ -486,7 +486,7 @@ WfConfig wf_config(crt_ctx *c, uint32_t n)
     // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
     // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
     int K = std::max(1, std::min(c->wf_pipes, (int)crt_ctx::kMaxPipes));
-    if (P < (1u << 18) || g.work_total < 6000000ull) K = 1;      // (1-2 spp of a 1080p frame: 7-10 % faster on one pipe)
+    if (P < (1u << 18) || (c->wf_pool == 0 && g.work_total < 6000000ull)) K = 1;   // (1-2 spp of a 1080p frame: 7-10 % faster on one pipe)
     // slots per pipe: a whole number of shade blocks for every one of the 64 shards when possible
     // (measured: a 1/8 strip takes 13.0 ms with such a pool and 15.1 ms with one 0.4 % smaller)
     uint32_t Pp = P / (uint32_t)K;

@@ -396,7 +396,7 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
     rng = np.random.default_rng(20260104)
     renderer.upload(ps).build_accel("bvh2")
     try:
-        for epoch in range(8):
+        for epoch in range(int(os.environ.get("CRT_TEST_EPOCHS", "8"))):
             opts = {"wf_pool": int(rng.choice([0, 1 << 18, 1 << 19])), "wf_pipes": int(rng.choice([1, 2])),
                     "wf_chunk": int(rng.choice([1, 2, 4])), "wf_park_its": int(rng.choice([0, 4, 1000])),
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
