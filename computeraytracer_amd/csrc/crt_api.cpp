@@ -480,8 +480,9 @@ WfConfig wf_config(crt_ctx *c, uint32_t n)
     g.npix_padded = g.tiles_x * g.tiles_y * 64u;
     g.npix = (size_t)c->tw * c->th;
     g.work_total = (unsigned long long)n * g.npix_padded;
-    // pool: about 1/8 of the batch's paths in flight, between 1 M and 4 M slots (measured best on S2)
-    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 22, std::max<unsigned long long>(1u << 20, g.work_total / 8u));
+    // pool: about 1/8 of the batch's paths in flight, between 1 M and 8 M slots (measured best on S2, whole
+    // frame and 1/2, 1/4, 1/8 shares, profiles/r01_steady_pool.log)
+    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 23, std::max<unsigned long long>(1u << 20, g.work_total / 8u));
     if ((unsigned long long)P > g.work_total) P = (uint32_t)g.work_total;
     // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
     // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
