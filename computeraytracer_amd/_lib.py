@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt.so")   # CRT_LIB: tuning builds only
 
 NCOUNTERS = 8
-ACCEL_NONE, ACCEL_BVH2 = 0, 1
+ACCEL_NONE, ACCEL_BVH2, ACCEL_LBVH = 0, 1, 2
 CNT = dict(rays=0, nodes=1, prims=2, paths=3, bounces=4, shadow=5, hits=6, walked=7)
 
 # name -> (restype, argtypes); kept in one place so tests can check that every

@@ -30,6 +30,7 @@ hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
 hipError_t wf_launch_finish(const WfParams &P, uint32_t max_paths, hipStream_t s);
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
+hipError_t build_lbvh(const float *lo, const float *hi, uint32_t n, Bvh &out, hipStream_t stream);
 }  // namespace crt
 
 using namespace crt;
@@ -91,6 +92,8 @@ struct crt_ctx {
     uint32_t W = 0, H = 0;
     bool have_scene = false;
     int accel_mode = -1;            // -1: not built
+    bool want_lbvh = false;         // crt_build_accel(CRT_ACCEL_LBVH): build the BVH2 on the GPU
+    int accel_builder = 0;          // 0: host binned SAH, 1: GPU LBVH
     Bvh bvh;
     Bvh4 bvh4;
     Bvh4Q bvh4q;
@@ -304,7 +307,15 @@ int upload_geometry(crt_ctx *c, int mode)
                 lo[3 * i + a] = l[a] - g; hi[3 * i + a] = h[a] + g;
             }
         }
-        build_bvh2(lo.data(), hi.data(), n, c->bvh);
+        c->accel_builder = 0;
+        if (c->want_lbvh && n >= 2) {
+            // GPU build (crt_lbvh.hip): same structure, so everything below is shared
+            hipError_t e = build_lbvh(lo.data(), hi.data(), n, c->bvh, c->stream);
+            if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? CRT_ENOMEM : CRT_EDEVICE, "crt_build_accel: GPU LBVH build: %s", hipGetErrorString(e));
+            c->accel_builder = 1;
+        } else {
+            build_bvh2(lo.data(), hi.data(), n, c->bvh);
+        }
         order = c->bvh.order;
     } else {
         order.resize(n);
@@ -1053,7 +1064,9 @@ int crt_build_accel(crt_ctx *c, int mode)
 {
     if (!c) return CRT_EINVAL;
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_build_accel: upload a scene first");
-    if (mode != CRT_ACCEL_NONE && mode != CRT_ACCEL_BVH2) return fail(c, CRT_EINVAL, "crt_build_accel: unknown mode %d", mode);
+    if (mode != CRT_ACCEL_NONE && mode != CRT_ACCEL_BVH2 && mode != CRT_ACCEL_LBVH) return fail(c, CRT_EINVAL, "crt_build_accel: unknown mode %d", mode);
+    c->want_lbvh = mode == CRT_ACCEL_LBVH;
+    if (mode == CRT_ACCEL_LBVH) mode = CRT_ACCEL_BVH2;          // same structure, same kernels
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1292,7 +1305,7 @@ int crt_accel_stats(crt_ctx *c, uint64_t out[8])
     out[4] = wide ? (c->bvh4q.ok ? 16 : 32) : 32;      // bytes of node data per child box tested
     out[5] = wide8 ? 8 : wide ? 4 : 2;                  // node width used by crt_trace
     out[6] = wide8 ? c->bvh8q.n_inner : wide ? c->bvh4.n_inner : c->bvh.n_inner;   // inner nodes of that tree
-    out[7] = 0;
+    out[7] = (uint64_t)c->accel_builder;               // 0: host binned SAH, 1: GPU LBVH
     out[0] = c->bvh.n_inner; out[1] = c->bvh.n_leaves; out[2] = c->bvh.max_depth;
     out[3] = (uint64_t)c->bvh.n_inner * 64u + (uint64_t)c->bvh4.n_inner * 128u + (uint64_t)c->prims.size() * 48u;
     return CRT_OK;

@@ -22,7 +22,7 @@
 namespace crt {
 
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-constexpr int kStackDepth = 32;
+constexpr int kStackDepth = 64;     // single-ray BVH2 walk: the SAH builder stops at depth 30, a GPU LBVH can reach 62
 constexpr uint32_t kNLambda = 301;
 constexpr uint32_t kNCie = 471;
 constexpr int CRT_NCOUNTERS_DEV = 16;   // 8 public (crt_counters) + 8 traversal-efficiency probes

@@ -14,10 +14,10 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ACCEL_BVH2, ACCEL_NONE, CNT, CrtError, NCOUNTERS
+from ._lib import ACCEL_BVH2, ACCEL_LBVH, ACCEL_NONE, CNT, CrtError, NCOUNTERS
 from .scene import PackedScene
 
-_ACCEL = {"none": ACCEL_NONE, "brute": ACCEL_NONE, "bvh2": ACCEL_BVH2, "bvh": ACCEL_BVH2,
+_ACCEL = {"none": ACCEL_NONE, "brute": ACCEL_NONE, "bvh2": ACCEL_BVH2, "bvh": ACCEL_BVH2, "lbvh": ACCEL_LBVH, ACCEL_LBVH: ACCEL_LBVH,
           ACCEL_NONE: ACCEL_NONE, ACCEL_BVH2: ACCEL_BVH2}
 
 
@@ -176,7 +176,8 @@ class Renderer:
         out = np.zeros(8, np.uint64)
         self._chk(self._lib.crt_accel_stats(self._h, out.ctypes.data))
         return dict(nodes=int(out[0]), leaves=int(out[1]), max_depth=int(out[2]), bytes=int(out[3]),
-                    bytes_per_box=int(out[4]), width=int(out[5]), wide_nodes=int(out[6]))
+                    bytes_per_box=int(out[4]), width=int(out[5]), wide_nodes=int(out[6]),
+                    builder=("sah-host", "lbvh-gpu")[int(out[7])])
 
     # -- test hooks
     def debug_intersect(self, origins, directions, exclude=None) -> np.ndarray:

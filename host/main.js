@@ -22,7 +22,7 @@ function loadAddon() {
   return addon;
 }
 
-const ACCEL = { none: 0, brute: 0, bvh2: 1, bvh: 1 };
+const ACCEL = { none: 0, brute: 0, bvh2: 1, bvh: 1, lbvh: 2 };
 
 function Main(options = {}) {
   const a = loadAddon();
