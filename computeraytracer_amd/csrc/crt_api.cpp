@@ -133,7 +133,7 @@ struct crt_ctx {
     DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[2];
     DevBuf<uint4> w_rng, w_misc;
     DevBuf<float2> w_hit;
-    DevBuf<uint32_t> w_vis, w_list_ext, w_list_sh;
+    DevBuf<uint32_t> w_vis, w_list_ext;
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
@@ -929,7 +929,7 @@ void crt_destroy(crt_ctx *c)
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); c->w_staging[0].release(); c->w_staging[1].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
-    c->w_vis.release(); c->w_list_ext.release(); c->w_list_sh.release(); c->w_wq.release();
+    c->w_vis.release(); c->w_list_ext.release(); c->w_wq.release();
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
         c->w_ctl[p].release();
         for (int b = 0; b < 2; b++) {
