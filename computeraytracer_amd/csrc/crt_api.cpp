@@ -130,7 +130,7 @@ struct crt_ctx {
     uint32_t wf_pool = 0;           // 0 = auto
     uint32_t wf_waves_per_cu = 14;  // per pipe
     int num_cu = 0;
-    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[2];
+    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing];
     DevBuf<uint4> w_rng, w_misc;
     DevBuf<float2> w_hit;
     DevBuf<uint32_t> w_vis, w_list_ext;
@@ -141,6 +141,7 @@ struct crt_ctx {
     int wf_tail_walk = 1;           // shade walks the ray lists once few paths are left
     int wf_park_its = 4;            // a batch parks when its queue holds less than this many iterations' worth
     int wf_chunk = 2;               // iterations enqueued per status readback (the host's decisions lag by two chunks)
+    int wf_ring = 4;                // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
     WfRun *run = nullptr;           // pipeline state between calls
     uint32_t wf_finish_at = 32768;  // paths of the previous batch left (per pipe) at which they move to the side pool; 0 = never
     uint32_t wf_flush_at = 4096;    // the same for the LAST batch at crt_sync (nothing to hide its tail under); 0 = never
@@ -407,11 +408,11 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
         HIPCHK(c, c->w_rng.alloc(P)); HIPCHK(c, c->w_misc.alloc(P)); HIPCHK(c, c->w_hit.alloc(P));
         HIPCHK(c, c->w_vis.alloc(P));
     }
-    for (int b = 0; b < 2; b++)
+    for (uint32_t b = 0; b < kWfRing; b++)
         if (c->w_staging[b].n < staging_elems) HIPCHK(c, c->w_staging[b].alloc(staging_elems));
     if (!c->w_wq.p) {
-        HIPCHK(c, c->w_wq.alloc(2));
-        HIPCHK(c, hipMemset(c->w_wq.p, 0, 2 * sizeof(WfWorkQ)));
+        HIPCHK(c, c->w_wq.alloc(kWfRing));
+        HIPCHK(c, hipMemset(c->w_wq.p, 0, kWfRing * sizeof(WfWorkQ)));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
             HIPCHK(c, c->w_ctl[p].alloc(1));
@@ -424,7 +425,7 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_evict[p], hipEventDisableTiming));
         }
         for (int p = 0; p < crt_ctx::kMaxPipes; p++)
-            for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[p][b], 2 * sizeof(WfWorkQ), hipHostMallocDefault));
+            for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[p][b], kWfRing * sizeof(WfWorkQ), hipHostMallocDefault));
     }
     if (c->num_cu == 0) {
         hipDeviceProp_t prop;
@@ -443,38 +444,48 @@ struct WfPipe {
     WfParams W{};
     hipStream_t stream = nullptr;
     uint32_t it = 0, chunk = 2, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
-    uint32_t it_fresh = 0;          // iterations >= it_fresh belong to the batch whose work queue is loaded
     int cur = 0;                    // status buffer of the chunk that is outstanding between driver passes
     bool done = false;              // no more chunks are enqueued for this pipe (drained, evicted or parked)
-    bool fresh = false;             // a status of the loaded batch has been read
-    unsigned long long rays = 0, old = 0;   // from the last status read: rays listed / paths of the previous batch alive
-    bool prev_dry = true;           // that status saw the previous batch's queue empty
+    bool any = false;               // a status has been read since the newest batch began
+    unsigned long long rays = 0;    // from the last status read: rays listed
+    unsigned long long old = 0;     // ... and paths of the OLDEST unresolved batch still in this pipe's pool
+    bool old_valid = false;         // ... counted by a launch that already knew which batch is the oldest
+    uint32_t old_from = 0;          // iterations >= old_from count survivors of the current oldest batch
+    bool dry[kWfRing] = {};         // a status of this pipe saw that batch's queue empty (its OWN snapshot: its
+                                    // survivor count only means something once no more such paths can start here)
     uint32_t evict_next = 0;        // evict_mask for the first shade launch of the next chunk
+    uint32_t it_confirmed = 0;      // iterations < it_confirmed are known to have completed (a status of them was read)
 };
 
-// A batch of samples whose paths are (or may still be) in flight; `open` until k_wf_resolve is enqueued for it.
-struct WfBatch { bool open = false; uint32_t n = 0, last_sample = 0, parity = 0; };
+// A batch of samples whose paths are (or may still be) in flight.
+struct WfBatch {
+    uint32_t n = 0, last_sample = 0, id = 0;
+    uint32_t from_it[crt_ctx::kMaxPipes] = {};   // per pipe: statuses of iterations >= from_it know this batch's queue
+};
 
-// The pipeline's state between driver calls.  A batch normally ENDS PARKED: its work queue is empty, its
-// paths are still in the pool, one chunk of iterations is still enqueued -- and the next batch's work flows
-// into the slots as they free up, so the pool never runs dry between batches.  Once only a few paths of the
-// parked batch are left, k_wf_shade moves them to the side pool, k_wf_finish runs them to their end on the
-// side stream and the batch is resolved: the path-length tail of a batch runs under the bulk of the next
-// one instead of on a nearly empty GPU.  wf_flush() does the same for the last batch (there is nothing to
-// hide it under); every call that reads or changes state flushes first.
+// The pipeline's state between driver calls.  Up to kWfRing batches are in flight, each with its own work
+// queue, staging buffer and side pools (indexed by the batch id, which a path carries in its flags).  A batch
+// normally ENDS PARKED: crt_trace returns while its queue still holds a few iterations' worth of work and one
+// chunk of iterations is enqueued; the next call publishes its queue and dead slots re-arm from the oldest
+// non-empty queue on -- the pool never runs dry between calls, however small the calls are.  Once only a few
+// paths of the OLDEST batch are left, k_wf_shade moves them to the side pool, k_wf_finish runs them to their
+// end and the batch is resolved (batches resolve in order: the accumulator is summed in sample order) --
+// the path-length tail of a batch runs under the bulk of the next ones instead of on a nearly empty GPU.
+// wf_flush() does the same for whatever is left at crt_sync; every call that reads or changes state flushes.
 struct WfRun {
     bool live = false;              // pipes are forked; every pipe has one outstanding chunk in status buffer [cur]
     int K = 0;
     uint32_t P = 0, Pp = 0, list_cap = 0, trace_blocks = 0;
-    uint32_t seg_wps[2] = {0, 0};           // per batch parity: work items per shard / in total
-    unsigned long long seg_total[2] = {0, 0};
+    uint32_t seg_wps[kWfRing] = {};             // per batch id: work items per shard / in total
+    unsigned long long seg_total[kWfRing] = {};
     WfPipe pipes[crt_ctx::kMaxPipes];
-    WfBatch cur, prev;
-    bool cur_left = false, prev_left = false;   // the loaded batch's / the previous batch's queue still holds work
-    bool work_left = false;                      // either of them
-    unsigned long long left_its = ~0ull;         // iterations until the loaded batch's queue is dry (estimate)
-    uint32_t rate_it = 0;                   // pipe 0's iteration and the work consumed at its last status
+    std::vector<WfBatch> open;                  // unresolved batches, oldest first; back() = the newest
+    bool queue_left[kWfRing] = {};              // pipe 0's view: that batch's queue still holds work
+    bool work_left = false;                     // any of them
+    unsigned long long left_its = ~0ull;        // iterations until the newest batch's queue is dry (estimate)
+    uint32_t rate_it = 0;                       // pipe 0's iteration and the newest batch's work consumed at its last status
     unsigned long long rate_consumed = 0;
+    uint32_t listed_until[kWfRing][crt_ctx::kMaxPipes] = {};   // per id and pipe: launches of iterations < this may look at that queue
 };
 
 struct WfConfig {
@@ -512,15 +523,13 @@ WfConfig wf_config(crt_ctx *c, uint32_t n)
     return g;
 }
 
-int wf_resolve_batch(crt_ctx *c, WfBatch &b)
+int wf_resolve_batch(crt_ctx *c, const WfBatch &b)
 {
     WfRun &r = *c->run;
-    if (!b.open) return CRT_OK;
     WfParams R = r.pipes[0].W;
-    R.batch_parity = b.parity; R.n_samples = b.n;
+    R.batch_parity = b.id; R.n_samples = b.n;
     HIPCHK(c, wf_launch_resolve(R, b.last_sample, c->stream));
     c->last_launches++;
-    b.open = false;
     return CRT_OK;
 }
 
@@ -535,7 +544,7 @@ int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
     for (uint32_t k = 0; k < pp.chunk; k++, pp.it++) {
         pp.W.evict_mask = pp.evict_next;
         HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
-        if (pp.evict_next) {                                     // the side stream may start once this launch is through
+        if (pp.evict_next) {                                     // k_wf_finish may start once this launch is through
             HIPCHK(c, hipEventRecord(c->ev_evict[p], pp.stream));
             pp.evict_next = 0; pp.W.evict_mask = 0;
         }
@@ -557,8 +566,9 @@ int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
         c->last_iterations++;
     }
     pp.it_end[buf] = pp.it;
+    for (uint32_t k = 0; k < pp.W.seg_n; k++) c->run->listed_until[pp.W.seg_order[k]][p] = pp.it;
     HIPCHK(c, hipMemcpyAsync(c->h_ctl[p][buf], pp.W.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, pp.stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_wq[p][buf], c->w_wq.p, 2 * sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_wq[p][buf], c->w_wq.p, kWfRing * sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
     HIPCHK(c, hipEventRecord(c->ev_ctl[p][buf], pp.stream));
     return CRT_OK;
 }
@@ -566,13 +576,13 @@ int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
 // After every pipe's evicting shade launch, run the evicted paths of batch `b` to their end and resolve the
 // batch -- on the context's stream, which has nothing else to do while the pipes work (a stream of its own
 // would be a fifth one, and streams beyond the hardware queues share one: a pipe queued behind a wait stalls).
-int wf_finish_side(crt_ctx *c, WfBatch &b, uint32_t max_paths, uint32_t paths_per_wave)
+int wf_finish_side(crt_ctx *c, const WfBatch &b, uint32_t max_paths, uint32_t paths_per_wave)
 {
     WfRun &r = *c->run;
     for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_evict[p], 0));
     for (int p = 0; p < r.K; p++) {
         WfParams F = r.pipes[p].W;
-        F.batch_parity = b.parity;
+        F.batch_parity = b.id;
         F.tail_bound = paths_per_wave;
         HIPCHK(c, wf_launch_finish(F, max_paths, c->stream));
         c->last_launches++;
@@ -580,8 +590,34 @@ int wf_finish_side(crt_ctx *c, WfBatch &b, uint32_t max_paths, uint32_t paths_pe
     return wf_resolve_batch(c, b);
 }
 
-// Enqueue iterations and read statuses until the loaded batch is parked (to_end = false: its queue is
-// empty and the previous batch is resolved) or finished and resolved (to_end = true).
+// The oldest batch is resolved: the next one becomes the one whose survivors the shade launches count.
+void wf_pop_oldest(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    r.open.erase(r.open.begin());
+    const uint32_t oldest = r.open.empty() ? 0u : r.open.front().id;
+    for (int p = 0; p < r.K; p++) {
+        WfPipe &pp = r.pipes[p];
+        pp.W.oldest_id = oldest;
+        pp.old_from = pp.it; pp.old_valid = false; pp.old = 0;
+    }
+}
+
+// Which queues the next chunks re-arm from: the open batches whose queue still holds work, oldest first.
+void wf_set_queues(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    uint32_t order[kWfRing], n = 0;
+    for (const WfBatch &b : r.open) if (r.queue_left[b.id] && n < kWfRing) order[n++] = b.id;
+    if (n == 0) order[n++] = r.open.empty() ? 0u : r.open.back().id;       // (all dry: any valid entry)
+    for (int p = 0; p < r.K; p++) {
+        for (uint32_t k = 0; k < kWfRing; k++) r.pipes[p].W.seg_order[k] = order[k < n ? k : n - 1];
+        r.pipes[p].W.seg_n = n;
+    }
+}
+
+// Enqueue iterations and read statuses until the newest batch is parked (to_end = false: its queue is nearly
+// empty and there is room for another batch) or everything is finished and resolved (to_end = true).
 int wf_drive(crt_ctx *c, bool to_end)
 {
     WfRun &r = *c->run;
@@ -590,79 +626,88 @@ int wf_drive(crt_ctx *c, bool to_end)
     const unsigned long long flush_at = std::min<unsigned long long>(c->wf_flush_at, kWfSideCap);
     int active = 0;
     for (int p = 0; p < K; p++) { r.pipes[p].done = false; active++; }
-    bool prev_evicting = false, cur_evicting = false;
+    bool oldest_evicting = false, all_evicting = false;
     while (active > 0) {
         for (int p = 0; p < K; p++)
             if (!r.pipes[p].done) { int rc = wf_enqueue_chunk(c, p, r.pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
-        // the chunk just enqueued carried the eviction of the previous batch's last paths: finish and resolve it
-        if (prev_evicting) { int rc = wf_finish_side(c, r.prev, kWfSideCap, c->wf_side_ppw); if (rc) return rc; prev_evicting = false; }
+        // the chunk just enqueued carried the eviction of the oldest batch's last paths: finish and resolve it
+        if (oldest_evicting) {
+            int rc = wf_finish_side(c, r.open.front(), kWfSideCap, c->wf_side_ppw);
+            if (rc) return rc;
+            wf_pop_oldest(c);
+            oldest_evicting = false;
+        }
         for (int p = 0; p < K; p++) {
             WfPipe &pp = r.pipes[p];
             if (pp.done) continue;
             HIPCHK(c, hipEventSynchronize(c->ev_ctl[p][pp.cur]));
-            if (pp.it_end[pp.cur] <= pp.it_fresh) { pp.cur ^= 1; continue; }      // a status from before this batch began
-            auto seg_left = [&](uint32_t par, unsigned long long &consumed) {
+            const uint32_t it_seen = pp.it_end[pp.cur];          // the status covers iterations < it_seen
+            pp.it_confirmed = it_seen;
+            const WfBatch &newest = r.open.back();
+            if (it_seen <= newest.from_it[p]) { pp.cur ^= 1; continue; }          // from before the newest batch began
+            auto seg_left = [&](uint32_t id, unsigned long long &consumed) {
                 bool left = false;
                 consumed = 0;
                 for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-                    const unsigned long long lo = (unsigned long long)sidx * r.seg_wps[par];
-                    const unsigned long long size = lo < r.seg_total[par] ? std::min<unsigned long long>(r.seg_wps[par], r.seg_total[par] - lo) : 0;
-                    const unsigned long long cur = c->h_wq[p][pp.cur][par].work[sidx].cur;
+                    const unsigned long long lo = (unsigned long long)sidx * r.seg_wps[id];
+                    const unsigned long long size = lo < r.seg_total[id] ? std::min<unsigned long long>(r.seg_wps[id], r.seg_total[id] - lo) : 0;
+                    const unsigned long long cur = c->h_wq[p][pp.cur][id].work[sidx].cur;
                     if (cur < size) left = true;
                     consumed += std::min(cur, size);
                 }
                 return left;
             };
-            // (each pipe judges the previous batch's queue by its OWN snapshot: its survivor count only means
-            // something once no more of that batch's paths can start in THIS pipe)
-            if (!pp.prev_dry) { unsigned long long d_ = 0; pp.prev_dry = !r.prev.open || !seg_left(r.prev.parity, d_); }
+            unsigned long long newest_consumed = 0;
+            for (const WfBatch &b : r.open) {
+                unsigned long long cons = 0;
+                const bool left = seg_left(b.id, cons);
+                if (!left) pp.dry[b.id] = true;
+                if (&b == &newest) newest_consumed = cons;
+                if (p == 0) r.queue_left[b.id] = left;          // monotone within a batch: once false it stays false
+            }
             if (p == 0) {
-                unsigned long long consumed = 0;
-                r.cur_left = seg_left(r.cur.parity, consumed);   // monotone within a batch: once false it stays false
-                r.prev_left = !pp.prev_dry;
-                r.work_left = r.cur_left || r.prev_left;
-                // How many iterations until the loaded batch's queue is dry.  Chunks shrink as that comes close when
-                // no further batch can take over (to_end): what is enqueued ahead of the status that shows the queue
-                // empty runs on a nearly empty pool, and the host needs only ~20 us per launch to keep up.
-                const uint32_t its = pp.it_end[pp.cur] - r.rate_it;
-                if (!r.cur_left) r.left_its = 0;
-                else if (its > 0 && consumed > r.rate_consumed) {
-                    const unsigned long long per_it = (consumed - r.rate_consumed) / its;
-                    r.left_its = (r.seg_total[r.cur.parity] - consumed) / std::max<unsigned long long>(per_it, 1);
+                r.work_left = false;
+                for (const WfBatch &b : r.open) r.work_left = r.work_left || r.queue_left[b.id];
+                // How many iterations until the newest batch's queue is dry.  Chunks shrink as that comes close when
+                // no further batch can take over: what is enqueued ahead of the status that shows the queues empty
+                // runs on a nearly empty pool, and the host needs only ~20 us per launch to keep up.
+                const uint32_t its = it_seen - r.rate_it;
+                if (!r.queue_left[newest.id]) r.left_its = 0;
+                else if (its > 0 && newest_consumed > r.rate_consumed) {
+                    const unsigned long long per_it = (newest_consumed - r.rate_consumed) / its;
+                    r.left_its = (r.seg_total[newest.id] - newest_consumed) / std::max<unsigned long long>(per_it, 1);
                 }
-                if (to_end || r.prev.open) {
+                if (to_end || r.open.size() >= (size_t)c->wf_ring) {
                     const uint32_t chunk = r.left_its >= 6 ? (uint32_t)c->wf_chunk : 1u;
                     for (int q = 0; q < K; q++) r.pipes[q].chunk = chunk;
                 }
-                r.rate_it = pp.it_end[pp.cur]; r.rate_consumed = consumed;
-                for (int q = 0; q < K; q++) {                     // which queues the next chunks re-arm from
-                    r.pipes[q].W.seg_first = r.prev_left ? r.prev.parity : r.cur.parity;
-                    r.pipes[q].W.seg_second = r.prev_left ? r.cur.parity : 2u;
-                }
+                r.rate_it = it_seen; r.rate_consumed = newest_consumed;
+                wf_set_queues(c);
             }
             const WfCtl *hc = c->h_ctl[p][pp.cur];
             unsigned long long rays = 0, old = 0;
             uint32_t bound = 0;
             for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-                const WfShard &sh = hc->shard[(pp.it_end[pp.cur] - 1) & 3u][sidx];
+                const WfShard &sh = hc->shard[(it_seen - 1) & 3u][sidx];
                 // per-shard bound for later iterations: slots never change shard and none are re-armed once the
-                // queue is empty, so no list of a shard can ever grow beyond the slots alive in it now
+                // queues are empty, so no list of a shard can ever grow beyond the slots alive in it now
                 uint32_t alive_here = 0;
                 for (int k = 0; k < 4; k++) { rays += sh.n[k]; alive_here += sh.n[k]; }
                 bound = std::max(bound, alive_here);
                 old += sh.old;
             }
-            pp.rays = rays; pp.old = old; pp.fresh = true;
-            if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu old %llu work_left %d bound %u\n", p, pp.it_end[pp.cur], rays, old, (int)r.work_left, bound);
-            // pipe 0's view of the queue can lag the others by a chunk; a pipe with no rays while work
+            pp.rays = rays; pp.any = true;
+            if (it_seen > pp.old_from) { pp.old = old; pp.old_valid = true; }
+            if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu old %llu open %zu work_left %d bound %u\n", p, it_seen, rays, old, r.open.size(), (int)r.work_left, bound);
+            // pipe 0's view of the queues can lag the others by a chunk; a pipe with no rays while work
             // may be left simply keeps going (its dead slots re-arm as soon as they see work)
-            if (!r.work_left && rays == 0) { pp.done = true; pp.old = 0; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
+            if (!r.work_left && rays == 0) { pp.done = true; pp.old = 0; pp.old_valid = true; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
             if (!to_end) {
-                // Park: the batch before this one is resolved and this one's queue is nearly dry -- NEARLY, so that the
-                // next call can publish its queue while this one still holds work and the chunk already enqueued
-                // ahead keeps the GPU busy: the pool never runs dry between batches.
-                if (!r.prev.open && r.left_its < (unsigned long long)c->wf_park_its) { pp.done = true; pp.cur ^= 1; active--; continue; }
-            } else if (!r.work_left && !cur_evicting) {
+                // Park: the newest batch's queue is nearly dry -- NEARLY, so that the next call can publish its
+                // queue while this one still holds work and the chunk already enqueued ahead keeps the GPU busy --
+                // and the ring has room for another batch.
+                if (r.open.size() < (size_t)c->wf_ring && r.left_its < (unsigned long long)c->wf_park_its) { pp.done = true; pp.cur ^= 1; active--; continue; }
+            } else if (!r.work_left && !all_evicting) {
                 if (rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull) && c->wf_tail_walk) {
                     // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
                     // the ray lists instead of the whole pool and the grids shrink.
@@ -670,37 +715,42 @@ int wf_drive(crt_ctx *c, bool to_end)
                     pp.blocks_now = (uint32_t)std::min<unsigned long long>(r.trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
                 }
             }
-            if (pp.it - pp.it_fresh > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+            if (pp.it - newest.from_it[p] > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
             pp.cur ^= 1;
         }
-        // Few paths of the previous batch are left in the pool (alive slots only shrink, so they still fit when
-        // the launch runs): the next shade launch of every pipe moves them to the side pool.
-        if (r.prev.open && !prev_evicting && active > 0) {
-            bool all_fresh = true;
+        // The oldest batch (when it is not the newest): its queue is dry for every pipe and few of its paths are
+        // left (alive slots only shrink, so they still fit when the launch runs) -- the next shade launch of every
+        // pipe moves them to the side pool; or none are left at all -- it is resolved right away.
+        if (r.open.size() > 1 && !oldest_evicting && !all_evicting && active > 0) {
+            const WfBatch &ob = r.open.front();
+            bool ready = true;
             unsigned long long old = 0, old_max = 0;
             for (int p = 0; p < K; p++) {
                 const WfPipe &pp = r.pipes[p];
                 if (pp.done) continue;                           // (a drained pipe holds no path at all)
-                all_fresh = all_fresh && pp.fresh && pp.prev_dry; old += pp.old; old_max = std::max(old_max, pp.old);
+                ready = ready && pp.old_valid && pp.dry[ob.id];
+                old += pp.old; old_max = std::max(old_max, pp.old);
             }
-            if (all_fresh && old == 0) { int rc = wf_resolve_batch(c, r.prev); if (rc) return rc; }
-            else if (all_fresh && old_max <= kWfSideCap && old <= evict_at * (unsigned)K) {
-                for (int p = 0; p < K; p++) if (!r.pipes[p].done) r.pipes[p].evict_next = 1u << r.prev.parity;
-                prev_evicting = true;
+            if (ready && old == 0) { int rc = wf_resolve_batch(c, ob); if (rc) return rc; wf_pop_oldest(c); }
+            else if (ready && old_max <= kWfSideCap && old <= evict_at * (unsigned)K) {
+                for (int p = 0; p < K; p++) if (!r.pipes[p].done) r.pipes[p].evict_next = 1u << ob.id;
+                oldest_evicting = true;
             }
         }
-        // to_end: once few paths are left altogether, everything alive goes to the side pool and the pool is done
-        if (to_end && !r.work_left && !cur_evicting && !prev_evicting && active > 0 && flush_at > 0) {
-            bool all_fresh = true, few = true;
+        // to_end: once few paths are left altogether, everything alive goes to the side pools and the pool is done
+        if (to_end && !r.work_left && !all_evicting && !oldest_evicting && active > 0 && flush_at > 0) {
+            bool ready = true;
             for (int p = 0; p < K; p++) {
                 if (r.pipes[p].done) continue;
-                all_fresh = all_fresh && r.pipes[p].fresh; few = few && r.pipes[p].rays <= flush_at;
+                ready = ready && r.pipes[p].any && r.pipes[p].rays <= flush_at;
             }
-            if (all_fresh && few) {
+            if (ready) {
+                uint32_t mask = 0;
+                for (const WfBatch &b : r.open) mask |= 1u << b.id;
                 for (int p = 0; p < K; p++) {
                     WfPipe &pp = r.pipes[p];
                     if (pp.done) continue;
-                    pp.evict_next = 3u;
+                    pp.evict_next = mask;
                     const uint32_t chunk = pp.chunk;
                     pp.chunk = 1;                                // one more iteration: its shade launch empties the pool
                     int rc = wf_enqueue_chunk(c, p, pp.cur ^ 1);
@@ -709,28 +759,25 @@ int wf_drive(crt_ctx *c, bool to_end)
                     pp.done = true; pp.rays = 0; pp.cur ^= 1;
                 }
                 active = 0;
-                cur_evicting = true;
+                all_evicting = true;
             }
         }
     }
-    bool empty = true;
+    bool empty = !r.work_left;
     for (int p = 0; p < K; p++) empty = empty && r.pipes[p].rays == 0;
     if (to_end || empty) {
-        if (cur_evicting) {
-            // (nothing else is running: few paths per wave end sooner)
-            int rc = r.prev.open ? wf_finish_side(c, r.prev, kWfSideCap, c->wf_flush_ppw) : CRT_OK;
-            if (rc == CRT_OK) rc = wf_finish_side(c, r.cur, (uint32_t)std::min<unsigned long long>(kWfSideCap, flush_at), c->wf_flush_ppw);
-            if (rc) return rc;
-        } else {
-            // everything enqueued for the pipes comes before the resolve pass on the context's stream
+        if (!all_evicting) {
+            // everything enqueued for the pipes comes before the resolve passes on the context's stream
             for (int p = 0; p < K; p++) {
                 HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
             }
-            int rc = wf_resolve_batch(c, r.prev);
+        }
+        while (!r.open.empty()) {                                // in order: the accumulator is summed in sample order
+            // (when everything was evicted nothing else is running: few paths per wave end sooner)
+            int rc = all_evicting ? wf_finish_side(c, r.open.front(), (uint32_t)flush_at, c->wf_flush_ppw) : wf_resolve_batch(c, r.open.front());
             if (rc) return rc;
-            rc = wf_resolve_batch(c, r.cur);
-            if (rc) return rc;
+            wf_pop_oldest(c);
         }
         if (c->counting) {
             // fold the pipes' counters into the context's
@@ -746,7 +793,7 @@ int wf_drive(crt_ctx *c, bool to_end)
             HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
         }
     }
-    if (to_end) {
+    if (to_end || empty) {
         // the pool is empty; the next batch sets the pipes up afresh (after everything enqueued here)
         for (int p = 0; p < K; p++) {
             HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
@@ -778,8 +825,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     // counting folds counters on the host after every batch; otherwise batches end parked
     const bool defer = c->wf_defer && !c->counting;
     const size_t staging_elems = (size_t)n * g.npix;
-    const uint32_t side_slots = 2u * (uint32_t)crt_ctx::kMaxPipes * kWfSideCap;   // side pools first, then the pool
-    if (r.live && (g.K != r.K || g.Pp != r.Pp || c->w_staging[0].n < staging_elems || r.prev.open)) {
+    const uint32_t side_slots = kWfRing * (uint32_t)crt_ctx::kMaxPipes * kWfSideCap;   // side pools first, then the pool
+    if (r.live && (g.K != r.K || g.Pp != r.Pp || c->w_staging[0].n < staging_elems || r.open.size() >= (size_t)c->wf_ring)) {
         int rc = wf_flush(c);
         if (rc) return rc;
     }
@@ -790,11 +837,14 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     if (!r.live) {
         r.K = g.K; r.P = g.P; r.Pp = g.Pp; r.list_cap = g.list_cap;
         r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
-        r.prev = WfBatch();
-        r.cur = WfBatch{true, n, c->sample + n, 0u};
+        r.open.clear();
+        WfBatch nb;
+        nb.n = n; nb.last_sample = c->sample + n; nb.id = 0;
+        r.open.push_back(nb);
         r.rate_it = 0;
         r.seg_total[0] = g.work_total; r.seg_wps[0] = g.work_per_shard;
-        r.cur_left = r.work_left = true; r.prev_left = false;
+        for (uint32_t b = 0; b < kWfRing; b++) { r.queue_left[b] = false; for (int p = 0; p < crt_ctx::kMaxPipes; p++) r.listed_until[b][p] = 0; }
+        r.queue_left[0] = r.work_left = true;
         for (int p = 0; p < r.K; p++) {
             r.pipes[p] = WfPipe();
             r.pipes[p].chunk = (uint32_t)c->wf_chunk;
@@ -806,9 +856,13 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             for (int b = 0; b < 2; b++)
                 for (int k = 0; k < 4; k++)
                     W.list[b][k] = c->w_list_ext.p + g.list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * g.list_cap * kWfShards;
-            W.staging[0] = c->w_staging[0].p; W.staging[1] = c->w_staging[1].p;
-            W.batch_parity = 0; W.keep_pool = 0; W.evict_mask = 0;
-            for (uint32_t b = 0; b < 2; b++) W.side_base[b] = (b * (uint32_t)crt_ctx::kMaxPipes + (uint32_t)p) * kWfSideCap;
+            for (uint32_t b = 0; b < kWfRing; b++) {
+                W.staging[b] = c->w_staging[b].p;
+                W.side_base[b] = (b * (uint32_t)crt_ctx::kMaxPipes + (uint32_t)p) * kWfSideCap;
+                W.seg[b] = WfSeg{0, 64, 0};
+                W.seg_order[b] = 0;
+            }
+            W.batch_parity = 0; W.oldest_id = 0; W.keep_pool = 0; W.evict_mask = 0;
             W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
             W.slot_base = side_slots + g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
             W.P = g.Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
@@ -816,8 +870,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.tiles_x = g.tiles_x; W.tiles_y = g.tiles_y; W.npix_padded = g.npix_padded;
             W.list_cap = g.list_cap;
             W.seg[0] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
-            W.seg[1] = WfSeg{0, 64, 0};
-            W.seg_first = 0; W.seg_second = 2;
+            W.seg_n = 1;
             W.n_samples = n;
             W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
             W.count = c->counting ? 1u : 0u;
@@ -837,7 +890,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             r.pipes[p].blocks_now = r.trace_blocks;
         }
         // The context's stream is the control stream: it resets the work queue and forks the pipes (and,
-        // later, resolves).  The pipes run on their own streams.
+        // later, finishes stragglers and resolves).  The pipes run on their own streams.
         HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int p = 0; p < r.K; p++) {
@@ -848,30 +901,38 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         for (int p = 0; p < r.K; p++) { rc = wf_enqueue_chunk(c, p, 0); if (rc) return rc; }
         r.live = true;
     } else {
-        // The parked batch becomes the previous one: its paths keep their slots (and their staging buffer)
-        // while this batch's work flows into the slots that are free.
-        r.prev = r.cur;
-        r.cur = WfBatch{true, n, c->sample + n, r.prev.parity ^ 1u};
-        const uint32_t np = r.cur.parity;
-        r.seg_total[np] = g.work_total; r.seg_wps[np] = g.work_per_shard;
-        r.prev_left = r.cur_left;                    // (the parked batch's queue may still hold work)
-        r.cur_left = r.work_left = true;
+        // The parked batches keep their slots, queues and staging buffers; this batch takes the next id and its
+        // work flows into the slots that are free once the older queues are dry.
+        WfBatch nb;
+        nb.n = n; nb.last_sample = c->sample + n; nb.id = (r.open.back().id + 1u) % kWfRing;
+        const uint32_t id = nb.id;
+        r.seg_total[id] = g.work_total; r.seg_wps[id] = g.work_per_shard;
+        r.queue_left[id] = r.work_left = true;
         for (int p = 0; p < r.K; p++) {
             WfPipe &pp = r.pipes[p];
-            pp.W.seg[np] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
+            nb.from_it[p] = pp.it;
+            pp.W.seg[id] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
             pp.W.n_samples = n;
-            pp.W.batch_parity = np; pp.W.keep_pool = 1;
-            pp.W.seg_first = r.prev_left ? r.prev.parity : np;
-            pp.W.seg_second = r.prev_left ? np : 2u;
+            pp.W.batch_parity = id; pp.W.keep_pool = 1;
             pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
-            pp.it_fresh = pp.it;
-            pp.fresh = false; pp.old = 0; pp.evict_next = 0; pp.chunk = (uint32_t)c->wf_chunk;
-            pp.prev_dry = !r.prev_left;
+            pp.any = false; pp.evict_next = 0; pp.chunk = (uint32_t)c->wf_chunk;
+            pp.dry[id] = false;
+            // (while it was the only batch, the oldest was also the newest and nothing was counted: the survivor
+            // counts of the oldest batch start with the launches enqueued from here on)
+            if (r.open.size() == 1) { pp.old_from = pp.it; pp.old_valid = false; pp.old = 0; }
         }
+        r.open.push_back(nb);
         r.rate_it = r.pipes[0].it;
-        // This batch's queue and side counters are reset on the control stream.  Nothing in flight looks at
-        // them: every kernel enqueued so far was told there is no second queue, and the batch that used this
-        // parity before is resolved.  The pipes only wait for the reset, not for each other.
+        wf_set_queues(c);
+        // This batch's queue and side counters are reset on the control stream.  The batch that used the id
+        // before is resolved; a launch still in flight may have that queue in its list, though (enqueued while
+        // it held work), and would take the NEW work with the OLD batch's parameters: the reset waits for such
+        // a pipe's outstanding chunk.  Otherwise the pipes only wait for the reset, not for each other.
+        for (int p = 0; p < r.K; p++)
+            if (r.listed_until[id][p] > r.pipes[p].it_confirmed) {
+                HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+            }
         for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->stream));   // (one block each)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
@@ -928,7 +989,7 @@ void crt_destroy(crt_ctx *c)
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
-    c->w_nee.release(); c->w_staging[0].release(); c->w_staging[1].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
+    c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
     c->w_vis.release(); c->w_list_ext.release(); c->w_wq.release();
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
         c->w_ctl[p].release();
@@ -1324,6 +1385,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_flush_at")) { c->wf_flush_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_side_ppw")) { c->wf_side_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_flush_ppw")) { c->wf_flush_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_ring")) { c->wf_ring = (int)std::min<int64_t>(kWfRing, std::max<int64_t>(2, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_chunk")) { c->wf_chunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_park_its")) { c->wf_park_its = (int)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_tail_walk")) { c->wf_tail_walk = value != 0; return CRT_OK; }

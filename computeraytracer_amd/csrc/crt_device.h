@@ -81,11 +81,12 @@ constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8
 // ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
 constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;
 constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
-constexpr uint32_t kWfBatchShift = 5;                           // 1 bit: which of the two batches in flight the path belongs to
+constexpr uint32_t kWfBatchShift = 5;                           // 2 bits: which of the (up to kWfRing) batches in flight the path belongs to
+constexpr uint32_t kWfRing = 4;                                 // batch ids cycle 0..kWfRing-1: queues, staging buffers, side pools are indexed by id
 // Stragglers: once only a few paths of a batch are left (its queue is long empty, the pool is busy with the
 // next batch), k_wf_shade moves them out of the pool into a small side pool, where k_wf_finish runs them to
 // their end on another stream.  Side-pool slots precede the pool in the same arrays:
-// [(parity*pipes + pipe)*kWfSideCap, +kWfSideCap).
+// [(id*pipes + pipe)*kWfSideCap, +kWfSideCap).
 constexpr uint32_t kWfSideCap = 65536;
 
 // Every queue counter is sharded kWfShards ways, one 128-byte line per shard: same-address
@@ -100,7 +101,7 @@ struct WfWork { uint32_t cur, pad[31]; };                    // next work item o
 struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
     unsigned long long counters[CRT_NCOUNTERS_DEV];
-    uint32_t side_count[2];          // paths moved to the side pool, per batch parity
+    uint32_t side_count[kWfRing];    // paths moved to the side pool, per batch id
 };
 // The work queue is shared by the pipes of a context (two half-pools run on two streams so that
 // one half's streaming shade pass overlaps the other half's latency-bound traversal).  There are two
@@ -124,15 +125,17 @@ struct WfParams {
     float2 *hit;
     uint32_t *vis;
     uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
-    float4 *staging[2];              // finished samples of the batch with parity 0 / 1 (two batches can be in flight)
-    uint32_t batch_parity;           // parity of the batch whose work queue is loaded (k_wf_resolve: the batch to resolve)
+    float4 *staging[kWfRing];        // finished samples, per batch id (several batches can be in flight)
+    uint32_t batch_parity;           // id of the newest batch (k_wf_init: the batch being set up; k_wf_resolve / k_wf_finish: the batch to resolve / finish)
+    uint32_t oldest_id;              // id of the oldest unresolved batch: k_wf_shade counts its surviving paths
     uint32_t keep_pool;              // k_wf_init: leave the slots and list counters alone (paths of the previous batch live on)
-    uint32_t side_base[2];           // first side-pool slot of this pipe, per batch parity
-    uint32_t evict_mask;             // k_wf_shade: bit b = move the alive paths of batch parity b to the side pool first
+    uint32_t side_base[kWfRing];     // first side-pool slot of this pipe, per batch id
+    uint32_t evict_mask;             // k_wf_shade: bit b = move the alive paths of batch id b to the side pool first
     WfCtl *ctl;
-    WfWorkQ *wq;                     // [2], by batch parity
-    WfSeg seg[2];
-    uint32_t seg_first, seg_second;  // parities of the queues dead slots re-arm from, in this order (second: 2 = none)
+    WfWorkQ *wq;                     // [kWfRing], by batch id
+    WfSeg seg[kWfRing];
+    uint32_t seg_order[kWfRing];     // ids of the queues dead slots re-arm from, oldest first
+    uint32_t seg_n;                  // how many of them
     uint32_t slot_base;              // this pipe's slots are [slot_base, slot_base + P)
     uint32_t reset_wq;               // k_wf_init also resets the work queue of batch_parity
     uint32_t P;                      // slots of this pipe

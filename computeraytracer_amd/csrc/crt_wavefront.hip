@@ -293,7 +293,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             const uint32_t tile = pp >> 6, l = pp & 63u;
             const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
             f3 c = spectral_to_xyz(S, R.radiance, wl);
-            P.staging[(R.flags >> kWfBatchShift) & 1u][(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
+            P.staging[(R.flags >> kWfBatchShift) & (kWfRing - 1u)][(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
             alive = false;
             if (COUNT) cn.paths++;
         }
@@ -308,16 +308,16 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         const bool want0 = in_pool && !alive;
         bool want = want0;
         const uint32_t lane = lane_id();
-        // up to two queues: the older batch's until it is dry, then the next batch's (published early)
-        uint32_t sg = P.seg_first;
+        // several queues: the oldest batch's until it is dry, then the next one's, ... (published early)
+        uint32_t si = 0, sg = P.seg_order[0];
         int tries = 0;
         bool dry = __hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        for (int attempt = 0; attempt < 6; attempt++) {
+        for (int attempt = 0; attempt < 3 * (int)kWfRing; attempt++) {
             if (dry) {
-                if (sg == P.seg_second || P.seg_second > 1u) break;
-                sg = P.seg_second; tries = 0;
+                if (++si >= P.seg_n) break;
+                sg = P.seg_order[si]; tries = 0;
                 dry = __hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-                if (dry) break;
+                if (dry) continue;
             }
             const unsigned long long m = __ballot(want);
             if (!m || tries >= 3) break;
@@ -416,7 +416,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
         P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
     }
-    const bool old = alive && ((R.flags >> kWfBatchShift) & 1u) != P.batch_parity;
+    const bool old = alive && ((R.flags >> kWfBatchShift) & (kWfRing - 1u)) == P.oldest_id && P.oldest_id != P.batch_parity;
     return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, old};
 }
 
@@ -463,9 +463,10 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         // The slot is then dead and is re-armed below like any other.
         uint4 misc = uint4{0, 0, 0, 0};
         if (in_pool) misc = P.misc[slot];
-        const uint32_t par = (misc.y >> kWfBatchShift) & 1u;
+        const uint32_t par = (misc.y >> kWfBatchShift) & (kWfRing - 1u);
         const bool go = in_pool && (misc.y & kWfAlive) && ((P.evict_mask >> par) & 1u);
-        for (uint32_t b = 0; b < 2u; b++) {
+        for (uint32_t b = 0; b < kWfRing; b++) {
+            if (!((P.evict_mask >> b) & 1u)) continue;
             const unsigned long long m = __ballot(go && par == b);
             if (!m) continue;
             uint32_t base = 0;
@@ -990,7 +991,7 @@ __global__ void k_wf_init(const WfParams P)
         WfCtl *c = P.ctl;
         if (!P.keep_pool)
             for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
-        if (i == 0) { c->side_count[P.batch_parity] = 0; if (!P.keep_pool) c->side_count[P.batch_parity ^ 1u] = 0; }
+        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_parity] = 0; else for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; }
         if (P.reset_wq) {
             P.wq[P.batch_parity].work[i].cur = 0;
             if (i == 0) P.wq[P.batch_parity].work_done = 0;

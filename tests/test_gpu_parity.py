@@ -356,7 +356,7 @@ def test_batches_pipelined_across_calls(renderer, orc):
             assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *frames[8])
             renderer.frame(1).sync()            # a different batch size continues correctly
             assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *frames[9])
-        # stream-ordered view of a bound output between calls
+        # stream-ordered view of a bound output between calls: a complete frame, at most wf_ring - 1 calls old
         renderer.set_option("wf_defer", 1)
         dev = torch.device("cuda", 0)
         acc_t = torch.zeros((640, 640, 4), dtype=torch.float32, device=dev)
@@ -364,30 +364,33 @@ def test_batches_pipelined_across_calls(renderer, orc):
         stream = torch.cuda.Stream(device=dev)  # (the null stream's handle is 0, which means "the context's own")
         torch.cuda.synchronize()
         renderer.set_stream(stream.cuda_stream)
-        renderer.upload(ps).build_accel("bvh2").bind_output(acc_t.data_ptr(), rgba_t.data_ptr())
-        seen = []
-        with torch.cuda.stream(stream):
-            for k in range(1, 5):
-                renderer.frame(2)
-                seen.append((k, rgba_t.clone()))  # enqueued on the same stream, no sync with the renderer
-        renderer.sync()
-        torch.cuda.synchronize()
-        for k, snap in seen:
-            snap = snap.cpu().numpy()
-            ok = [j for j in range(max(1, k - 1), k + 1) if np.array_equal(snap, frames[2 * j][1])]
-            assert ok or (k == 1 and not snap.any()), f"after call {k} the bound framebuffer is neither frame {k - 1} nor frame {k}"
+        for ring in (2, 4):
+            renderer.set_option("wf_ring", ring)
+            acc_t.zero_(); rgba_t.zero_(); torch.cuda.synchronize()
+            renderer.upload(ps).build_accel("bvh2").bind_output(acc_t.data_ptr(), rgba_t.data_ptr())
+            seen = []
+            with torch.cuda.stream(stream):
+                for k in range(1, 5):
+                    renderer.frame(2)
+                    seen.append((k, rgba_t.clone()))  # enqueued on the same stream, no sync with the renderer
+            renderer.sync()
+            torch.cuda.synchronize()
+            for k, snap in seen:
+                snap = snap.cpu().numpy()
+                ok = [j for j in range(max(1, k - ring + 1), k + 1) if np.array_equal(snap, frames[2 * j][1])]
+                assert ok or (k < ring and not snap.any()), f"ring {ring}: after call {k} the bound framebuffer is no complete frame of the last {ring} calls"
         assert np.array_equal(rgba_t.cpu().numpy(), frames[8][1])
         assert np.array_equal(bits(acc_t.cpu().numpy())[..., :3], bits(frames[8][0])[..., :3])
     finally:
         renderer.set_stream(None)
-        renderer.set_option("wf_defer", 1)
+        renderer.set_option("wf_defer", 1).set_option("wf_ring", 4)
 
 
 def test_pipeline_state_machine_random_walk(renderer, orc):
     """Seeded random sequences of crt_trace calls of changing size, with syncs / reads in between or not, over
     random pipeline settings (pool size, pipes, chunk size, park threshold, eviction thresholds, tiles): after
-    each sequence the frame is the oracle's, bit for bit.  (Two batches in flight, two work queues, side pools,
-    eviction under the next batch and the flush at sync all have to agree for that.)"""
+    each sequence the frame is the oracle's, bit for bit.  (Several batches in flight, a work queue each, side
+    pools, eviction under the next batches and the flush at sync all have to agree for that.)"""
     from computeraytracer_amd import cornell
     W = H = 448
     ps = cornell(W, H)
@@ -400,7 +403,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             opts = {"wf_pool": int(rng.choice([0, 1 << 18, 1 << 19])), "wf_pipes": int(rng.choice([1, 2])),
                     "wf_chunk": int(rng.choice([1, 2, 4])), "wf_park_its": int(rng.choice([0, 4, 1000])),
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
-                    "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0]))}
+                    "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0])),
+                    "wf_ring": int(rng.choice([2, 3, 4]))}
             for k, v in opts.items():
                 renderer.set_option(k, v)
             rect = None
@@ -411,8 +415,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             else:
                 renderer.set_tile(0, 0, W, H)
             total = 0
-            for _ in range(int(rng.integers(2, 7))):
-                n = int(rng.choice([1, 2, 2, 3, 5]))
+            for _ in range(int(rng.integers(2, 12))):
+                n = int(rng.choice([1, 1, 2, 2, 3, 5]))
                 renderer.frame(n)
                 total += n
                 what = rng.random()
@@ -428,7 +432,7 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             assert renderer.sample == total
     finally:
         for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 2, "wf_park_its": 4, "wf_finish_at": 32768,
-                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1}.items():
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 4}.items():
             renderer.set_option(k, v)
 
 
