@@ -91,9 +91,9 @@ def main():
     # A step = one frame() of args.spp samples + the path's one exchange step, the all_gather of the rgba8
     # strips (RCCL over xGMI; the accumulator stays on its GPU like the reference's and is gathered once at
     # the end).  Steps are software-pipelined the way a display loop is: crt_trace returns with the frame's
-    # last, longest paths still in flight (they finish under the next frame), so the gather issued after
-    # frame k ships frame k-1 -- complete, in stream order -- and frame K-1 is shipped after the final sync.
-    # K frames traced, K complete frames gathered, all inside the timed region.
+    # last, longest paths still in flight (they finish under the next frames), so the gather issued after
+    # frame k ships the latest COMPLETE frame in stream order (k-1 in practice) and frame K-1 is shipped
+    # after the final sync.  K frames traced and completed, K gathers, all inside the timed region.
     trace = os.environ.get("CRT_BENCH_TRACE") == "1"
 
     def run_steps(k):

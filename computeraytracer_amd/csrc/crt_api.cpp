@@ -502,10 +502,12 @@ WfConfig wf_config(crt_ctx *c, uint32_t n)
     g.npix_padded = g.tiles_x * g.tiles_y * 64u;
     g.npix = (size_t)c->tw * c->th;
     g.work_total = (unsigned long long)n * g.npix_padded;
-    // pool: about 1/8 of the batch's paths in flight, between 1 M and 8 M slots (measured best on S2, whole
-    // frame and 1/2, 1/4, 1/8 shares, profiles/r01_steady_pool.log)
-    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 23, std::max<unsigned long long>(1u << 20, g.work_total / 8u));
-    if ((unsigned long long)P > g.work_total) P = (uint32_t)g.work_total;
+    // pool: about 1/4 of the batch's paths in flight, between 1 M and 8 M slots (measured best on S2 with up to
+    // four batches in flight: whole frame and 1/2, 1/4, 1/8 shares, profiles/r01_steady_pool.log)
+    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 23, std::max<unsigned long long>(1u << 20, g.work_total / 4u));
+    // (an explicit pool may exceed one batch's work: several batches share it, but never more than the ring holds)
+    const unsigned long long most = c->wf_pool ? g.work_total * (unsigned long long)std::max(1, c->wf_ring - 1) : g.work_total;
+    if ((unsigned long long)P > most) P = (uint32_t)most;
     // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
     // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
     int K = std::max(1, std::min(c->wf_pipes, (int)crt_ctx::kMaxPipes));

@@ -113,13 +113,15 @@ int crt_reset(crt_ctx *ctx);
  * framebuffer holds the tone-mapped average after the last one.
  * Asynchronous, and (option "wf_defer", default 1) PIPELINED across calls: a call
  * returns once its samples' work queue is nearly empty; the rest of its work and its
- * last, longest paths finish under the next crt_trace call, or in crt_sync.  So:
+ * last, longest paths finish under the following crt_trace calls (up to "wf_ring" = 4
+ * calls' batches are in flight, resolved in order), or in crt_sync.  So:
  *   - after crt_sync (or any crt_read_*, crt_counters, crt_last_*_ms) the buffers
  *     hold every sample requested so far;
  *   - in between, buffers bound with crt_bind_output hold, in stream order, the
- *     complete frame of an EARLIER crt_trace call (at least the one before the
- *     last) -- never a half-resolved one.  A display/gather loop that shows frame
- *     k-1 while frame k renders needs no sync at all. */
+ *     complete frame of an EARLIER crt_trace call -- at most wf_ring - 1 calls before
+ *     the last one, in practice the one before -- never a half-resolved one.  A
+ *     display/gather loop that shows the latest complete frame while the next ones
+ *     render needs no sync at all. */
 int crt_trace(crt_ctx *ctx, uint32_t n_samples);
 /* Finish everything requested so far and wait for it. */
 int crt_sync(crt_ctx *ctx);
@@ -169,7 +171,7 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
  * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
  * (0 = auto); "wf_waves_per_cu": persistent traversal waves per CU; "wf_pipes": half-pools
  * on separate streams; "wf_defer": 0 = every crt_trace call runs its paths to the end;
- * "wf_chunk" (iterations enqueued per status readback), "wf_park_its", "wf_finish_at",
+ * "wf_ring" (2..4 batches in flight), "wf_chunk" (iterations enqueued per status readback), "wf_park_its", "wf_finish_at",
  * "wf_flush_at", "wf_side_ppw", "wf_flush_ppw", "wf_tail_walk": pipeline tuning;
  * "quantize", "wf_width" (4 | 8: node width of the wavefront traversal; at crt_build_accel);
  * "time_kernels".  Setting an option first finishes what is in flight. */

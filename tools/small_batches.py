@@ -1,8 +1,8 @@
-"""Small batches (1-4 spp per call at 1080p): pool size and pipes, steady state (60 pipelined calls + sync)."""
+"""Small batches (1-8 spp per call at 1080p): pool size, pipes and ring depth, steady state (60 pipelined calls + sync)."""
 import sys, time
 sys.path.insert(0, '.')
 from computeraytracer_amd import Renderer, scenes_synth
-name = sys.argv[1] if len(sys.argv) > 1 else 'mesh10k'
+name = sys.argv[1] if len(sys.argv) > 1 else 'atrium250k'
 ps = scenes_synth.SCENES[name](1920, 1080); r = Renderer(0); r.upload(ps).build_accel('bvh2')
 def t(spp, calls=60, n=2):
     best = 1e9
@@ -13,10 +13,11 @@ def t(spp, calls=60, n=2):
         r.sync()
         best = min(best, (time.perf_counter() - t0) * 1e3 / calls)
     return best
-for spp in (1, 2, 4, 8):
-    out = []
-    for pool in (0, 1 << 20, 1 << 21, 1 << 22):
-        for pipes in (1, 2):
-            r.set_option('wf_pool', pool).set_option('wf_pipes', pipes)
-            out.append('%.0fM/%d: %.2f' % (pool / 2**20, pipes, t(spp)))
-    print(name, spp, 'spp |', ' | '.join(out), flush=True)
+for spp in (1, 2):
+    for ring in (4,):
+        out = []
+        for pool in (0, 1 << 21, 3 << 20, 1 << 22, 6 << 20):
+            for pipes in (1, 2):
+                r.set_option('wf_pool', pool).set_option('wf_pipes', pipes).set_option('wf_ring', ring)
+                out.append('%.0fM/%d: %.2f' % (pool / 2**20, pipes, t(spp)))
+        print(name, spp, 'spp ring', ring, '|', ' | '.join(out), flush=True)
