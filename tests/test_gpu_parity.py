@@ -386,6 +386,28 @@ def test_batches_pipelined_across_calls(renderer, orc):
         renderer.set_option("wf_defer", 1).set_option("wf_ring", 4)
 
 
+def test_pipelined_calls_at_full_scale(renderer):
+    """S2 at 1080p with the default settings (two pipes, 8 M-slot pool, four batches in flight, eviction under
+    the next batches): calls of changing size back to back equal one fused call, bit for bit."""
+    from computeraytracer_amd.scenes_synth import atrium250k
+    ps = atrium250k(1920, 1080)
+    a, r8 = render(renderer, ps, 30)
+    renderer.reset()
+    for n in (8, 8, 4, 1, 1, 8):
+        renderer.frame(n)
+    renderer.sync()
+    assert renderer.sample == 30
+    assert np.array_equal(bits(renderer.read_accum()), bits(a)) and np.array_equal(renderer.read_rgba8(), r8)
+    renderer.set_row_bands(8, 8, 5)             # the 1/8 share of an 8-GPU run: small batches, pool = a quarter of one
+    renderer.frame(12).sync()
+    a12, r12 = renderer.read_accum(), renderer.read_rgba8()
+    renderer.reset()
+    for n in (4, 4, 2, 2):
+        renderer.frame(n)
+    renderer.sync()
+    assert np.array_equal(bits(renderer.read_accum()), bits(a12)) and np.array_equal(renderer.read_rgba8(), r12)
+
+
 def test_pipeline_state_machine_random_walk(renderer, orc):
     """Seeded random sequences of crt_trace calls of changing size, with syncs / reads in between or not, over
     random pipeline settings (pool size, pipes, chunk size, park threshold, eviction thresholds, tiles): after
