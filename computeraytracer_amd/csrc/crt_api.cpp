@@ -143,7 +143,7 @@ struct crt_ctx {
     int wf_chunk = 2;               // iterations enqueued per status readback (the host's decisions lag by two chunks)
     int wf_ring = 4;                // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
     WfRun *run = nullptr;           // pipeline state between calls
-    uint32_t wf_finish_at = 32768;  // paths of the previous batch left (per pipe) at which they move to the side pool; 0 = never
+    uint32_t wf_finish_at = 32768;  // paths of the oldest batch left (per pipe) at which they move to the side pool; 0 = never
     uint32_t wf_flush_at = 4096;    // the same for the LAST batch at crt_sync (nothing to hide its tail under); 0 = never
     uint32_t wf_side_ppw = 64, wf_flush_ppw = 4;   // k_wf_finish: paths per wave, under the next batch / at crt_sync
     DevBuf<WfCtl> w_ctl[kMaxPipes];
@@ -529,7 +529,7 @@ int wf_resolve_batch(crt_ctx *c, const WfBatch &b)
 {
     WfRun &r = *c->run;
     WfParams R = r.pipes[0].W;
-    R.batch_parity = b.id; R.n_samples = b.n;
+    R.batch_id = b.id; R.n_samples = b.n;
     HIPCHK(c, wf_launch_resolve(R, b.last_sample, c->stream));
     c->last_launches++;
     return CRT_OK;
@@ -584,7 +584,7 @@ int wf_finish_side(crt_ctx *c, const WfBatch &b, uint32_t max_paths, uint32_t pa
     for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_evict[p], 0));
     for (int p = 0; p < r.K; p++) {
         WfParams F = r.pipes[p].W;
-        F.batch_parity = b.id;
+        F.batch_id = b.id;
         F.tail_bound = paths_per_wave;
         HIPCHK(c, wf_launch_finish(F, max_paths, c->stream));
         c->last_launches++;
@@ -864,7 +864,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
                 W.seg[b] = WfSeg{0, 64, 0};
                 W.seg_order[b] = 0;
             }
-            W.batch_parity = 0; W.oldest_id = 0; W.keep_pool = 0; W.evict_mask = 0;
+            W.batch_id = 0; W.oldest_id = 0; W.keep_pool = 0; W.evict_mask = 0;
             W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
             W.slot_base = side_slots + g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
             W.P = g.Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
@@ -915,7 +915,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             nb.from_it[p] = pp.it;
             pp.W.seg[id] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
             pp.W.n_samples = n;
-            pp.W.batch_parity = id; pp.W.keep_pool = 1;
+            pp.W.batch_id = id; pp.W.keep_pool = 1;
             pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
             pp.any = false; pp.evict_next = 0; pp.chunk = (uint32_t)c->wf_chunk;
             pp.dry[id] = false;

@@ -76,7 +76,7 @@ struct TraceParams {
 //   hit     (t, hit slot bits)            written by the trace kernel for extension rays
 //   vis     in: light primitive index, out: 1 = light visible    (shadow rays)
 //   list[parity][class]                   slots with an active ray this iteration (ballot/popc compacted)
-//   staging[b] (xyz, -) per (sample, pixel)  finished samples of batch parity b, summed in sample order by k_wf_resolve
+//   staging[b] (xyz, -) per (sample, pixel)  finished samples of the batch with id b, summed in sample order by k_wf_resolve
 constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
 // ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
 constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;
@@ -95,7 +95,7 @@ constexpr uint32_t kWfSideCap = 65536;
 // the ray lists; traversal waves and re-arming waves pick a non-empty shard with one
 // wave-wide load + ballot.
 constexpr uint32_t kWfShards = 64;
-// rays listed by shade per class / fetch cursor of trace / slots still alive for the PREVIOUS batch
+// rays listed by shade per class / fetch cursor of trace / slots still alive for the OLDEST unresolved batch
 struct WfShard { uint32_t n[4], cur, old, pad[26]; };
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
@@ -104,14 +104,14 @@ struct WfCtl {                       // device control block, one per context
     uint32_t side_count[kWfRing];    // paths moved to the side pool, per batch id
 };
 // The work queue is shared by the pipes of a context (two half-pools run on two streams so that
-// one half's streaming shade pass overlaps the other half's latency-bound traversal).  There are two
-// of them, one per batch parity: the next batch's work is published while the current batch's queue
+// one half's streaming shade pass overlaps the other half's latency-bound traversal).  There are kWfRing
+// of them, one per batch id: the next batch's work is published while the current batch's queue
 // still holds a few iterations' worth, so the pool never runs dry between batches.
 struct WfWorkQ {
     WfWork work[kWfShards];
     uint32_t work_done, pad_[31];    // set once every work shard is exhausted (saves the scans)
 };
-// One batch's share of the parameters (indexed by batch parity like the queues and the staging buffers).
+// One batch's share of the parameters (indexed by batch id like the queues and the staging buffers).
 struct WfSeg {
     unsigned long long work_total;   // n_samples * npix_padded
     uint32_t work_per_shard;         // work items per shard (multiple of 64)
@@ -126,9 +126,9 @@ struct WfParams {
     uint32_t *vis;
     uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
     float4 *staging[kWfRing];        // finished samples, per batch id (several batches can be in flight)
-    uint32_t batch_parity;           // id of the newest batch (k_wf_init: the batch being set up; k_wf_resolve / k_wf_finish: the batch to resolve / finish)
+    uint32_t batch_id;           // id of the newest batch (k_wf_init: the batch being set up; k_wf_resolve / k_wf_finish: the batch to resolve / finish)
     uint32_t oldest_id;              // id of the oldest unresolved batch: k_wf_shade counts its surviving paths
-    uint32_t keep_pool;              // k_wf_init: leave the slots and list counters alone (paths of the previous batch live on)
+    uint32_t keep_pool;              // k_wf_init: leave the slots and list counters alone (paths of the batches before live on)
     uint32_t side_base[kWfRing];     // first side-pool slot of this pipe, per batch id
     uint32_t evict_mask;             // k_wf_shade: bit b = move the alive paths of batch id b to the side pool first
     WfCtl *ctl;
@@ -137,7 +137,7 @@ struct WfParams {
     uint32_t seg_order[kWfRing];     // ids of the queues dead slots re-arm from, oldest first
     uint32_t seg_n;                  // how many of them
     uint32_t slot_base;              // this pipe's slots are [slot_base, slot_base + P)
-    uint32_t reset_wq;               // k_wf_init also resets the work queue of batch_parity
+    uint32_t reset_wq;               // k_wf_init also resets the work queue of batch_id
     uint32_t P;                      // slots of this pipe
     uint32_t x0, y0, tw, th;         // tile rectangle (local buffer is tw x th)
     uint32_t band, stride, phase;    // row interleave: global y = y0 + (ly/band)*band*stride + phase*band + ly%band

@@ -416,7 +416,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
         P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
     }
-    const bool old = alive && ((R.flags >> kWfBatchShift) & (kWfRing - 1u)) == P.oldest_id && P.oldest_id != P.batch_parity;
+    const bool old = alive && ((R.flags >> kWfBatchShift) & (kWfRing - 1u)) == P.oldest_id && P.oldest_id != P.batch_id;
     return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, old};
 }
 
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         const bool cl0 = emit_ext && ext_primary, cl1 = emit_ext && !ext_primary;
         const bool cl2 = emit_sh && sh_primary, cl3 = emit_sh && !sh_primary;
         const unsigned long long m0 = __ballot(cl0), m1 = __ballot(cl1), m2 = __ballot(cl2), m3 = __ballot(cl3);
-        const unsigned long long mo = __ballot(so.old);          // paths of the previous batch still in the pool
+        const unsigned long long mo = __ballot(so.old);          // paths of the oldest unresolved batch still in the pool
         WfShard &sh = ctl->shard[ring][my_shard];
         uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (lane == 0) {
@@ -916,9 +916,9 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P)
     // P.tail_bound = paths per wave: a wave runs until its longest path ends and every bounce costs the
     // slowest lane's walk, so when the GPU has nothing else to do few paths per wave finish sooner
     const uint32_t j = blockIdx.x * P.tail_bound + threadIdx.x;
-    const uint32_t count = min(ctl->side_count[P.batch_parity], kWfSideCap);
+    const uint32_t count = min(ctl->side_count[P.batch_id], kWfSideCap);
     const bool mine = threadIdx.x < P.tail_bound && j < count;
-    const uint32_t slot = P.side_base[P.batch_parity] + (mine ? j : 0u);
+    const uint32_t slot = P.side_base[P.batch_id] + (mine ? j : 0u);
     uint32_t flags = 0;
     if (mine) flags = P.misc[slot].y;
     bool alive = mine && (flags & kWfAlive);
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t l
     if (pix >= npix) return;
     const float4 a4 = P.accum[pix];
     f3 acc = f3{a4.x, a4.y, a4.z};
-    const float4 *__restrict__ staging = P.staging[P.batch_parity];
+    const float4 *__restrict__ staging = P.staging[P.batch_id];
     for (uint32_t s = 0; s < P.n_samples; s++) {
         const float4 v = staging[(size_t)s * npix + pix];
         acc = acc + f3{v.x, v.y, v.z};                           // :108, in sample order
@@ -991,10 +991,10 @@ __global__ void k_wf_init(const WfParams P)
         WfCtl *c = P.ctl;
         if (!P.keep_pool)
             for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
-        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_parity] = 0; else for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; }
+        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; }
         if (P.reset_wq) {
-            P.wq[P.batch_parity].work[i].cur = 0;
-            if (i == 0) P.wq[P.batch_parity].work_done = 0;
+            P.wq[P.batch_id].work[i].cur = 0;
+            if (i == 0) P.wq[P.batch_id].work_done = 0;
         }
     }
 }
