@@ -199,7 +199,11 @@ def main():
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
                        "partition": (f"rows dealt to {world} GPUs in bands of {args.band}" if world > 1 and args.band else f"{world} horizontal strip(s)")
                                     + ", scene replicated, all_gather of the rgba8 strips per step",
-                       "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s)" % t_build},
+                       "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s)" % t_build,
+                       "pipelining": "steps are software-pipelined like a display loop: frame() returns with the frame's longest "
+                                     "paths still in flight (they finish under the next frames); the gather after frame k ships the "
+                                     "latest complete frame, the last frame is shipped after the final sync; every frame is complete "
+                                     "and gathered inside the timed region"},
             "mpaths_per_s": round(paths / elapsed / 1e6, 3),
             "rays_per_path": round(rays / max(paths, 1), 3),
             "rays": {"intersect_calls": int(rays), "walked_bvh": int(walked), "shadow": int(shadow),
