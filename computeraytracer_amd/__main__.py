@@ -13,7 +13,7 @@ def main():
     ap.add_argument("--width", type=int)
     ap.add_argument("--height", type=int)
     ap.add_argument("--spp", type=int, default=64)
-    ap.add_argument("--accel", default="bvh2", choices=["bvh2", "none"])
+    ap.add_argument("--accel", default="bvh2", choices=["bvh2", "lbvh", "none"])
     ap.add_argument("--out", default="render.png")
     ap.add_argument("--checkpoint", default=None, help="resume from / save to this .npz")
     args = ap.parse_args()

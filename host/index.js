@@ -1,6 +1,6 @@
 #!/usr/bin/env node
 'use strict';
-// CLI: node host/index.js [--scene file.json] [--width W --height H] [--spp N] [--accel bvh2|none]
+// CLI: node host/index.js [--scene file.json] [--width W --height H] [--spp N] [--accel bvh2|lbvh|none]
 //                         [--out image.ppm] [--dump prefix] [--pack-only prefix]
 const fs = require('fs');
 const { Main, writePPM } = require('./main');
