@@ -47,6 +47,9 @@ namespace crt {
 #ifndef CRT_WF_LEAF_AT
 #define CRT_WF_LEAF_AT 32
 #endif
+#ifndef CRT_WF_SPEC
+#define CRT_WF_SPEC 1
+#endif
 #ifndef CRT_WF_SHADE_BLOCK
 #define CRT_WF_SHADE_BLOCK 256
 #endif
@@ -57,6 +60,7 @@ namespace crt {
 #define CRT_WF_MIN_WAVES 1
 #endif
 constexpr int kWfStack = CRT_WF_STACK;      // LDS stack entries per lane (BVH depth is capped by the builder)
+constexpr int kNoNode = 0x7FFFFFFF;          // "no node left to walk" (inner ids are smaller, leaf references negative)
 constexpr int kTraceChunk = 128;            // list entries a wave reserves per atomic
 constexpr int kRefillAt = CRT_WF_REFILL;    // refill when at least this many lanes are idle
 
@@ -602,6 +606,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
         have_shard = sh_total > 0u;
     }
     bool active = false;
+    int pend = 0;                                   // a leaf put aside (CRT_WF_SPEC), 0 = none
     // per-lane ray + traversal state
     f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, id = f3{0, 0, 0}, oid = f3{0, 0, 0};
     uint32_t excl = 0, slot = 0, b_index = kNoHit, b_slot = kNoHit, b_slot_in = kNoHit;
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                         else if (nprim == 0u) { g_hit[slot] = float2{t_max, bits_f(kNoHit)}; active = false; }
                     }
                     b_slot_in = b_slot;
-                    node = root; sp = 0;
+                    node = root; sp = 0; pend = 0;
                     const float tiny = 1.0e-20f;
                     id.x = 1.0f / (abs_(d.x) > tiny ? d.x : __builtin_copysignf(tiny, d.x));
                     id.y = 1.0f / (abs_(d.y) > tiny ? d.y : __builtin_copysignf(tiny, d.y));
@@ -694,20 +699,30 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
         //      lanes hold one (or nothing else can run), so both code blocks run with many lanes on.
 #pragma unroll 1
         for (int pass = 0; pass < 64; pass++) {
-            const bool inner = active && node >= 0;
-            const bool leaf = active && node < 0;
-            const int ni = __popcll(__ballot(inner)), nl = __popcll(__ballot(leaf));
-            if (ni + nl == 0) break;
-            if (!exhausted && 64 - (ni + nl) >= kRefillAt && pass > 0) break;     // enough idle lanes: refill first
+#if CRT_WF_SPEC
+            // A lane that reaches a leaf puts it aside (one per lane) and goes on with the next node of its stack
+            // instead of idling until enough lanes hold a leaf: the closest hit does not depend on the order, only
+            // t_max shrinks a little later.
+            if (active && node < 0 && pend == 0 && sp > 0) {
+                pend = node;
+                sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
+            }
+#endif
+            const bool inner = active && node >= 0 && node != kNoNode;
+            const bool leaf = active && (node < 0 || pend != 0);
+            const int ni = __popcll(__ballot(inner)), nl = __popcll(__ballot(leaf)), nb = __popcll(__ballot(inner || leaf));
+            if (nb == 0) break;
+            if (!exhausted && 64 - nb >= kRefillAt && pass > 0) break;            // enough idle lanes: refill first
             if (nl >= CRT_WF_LEAF_AT || ni == 0) {
                 if (COUNT) {
                     d_leaf_it++; d_leaf_act += (uint32_t)nl;
-                    uint32_t mc = leaf ? ((~(uint32_t)node) & 7u) + 1u : 0u;
+                    uint32_t mc = leaf ? ((~(uint32_t)(pend != 0 ? pend : node)) & 7u) + 1u : 0u;
                     for (int off = 32; off > 0; off >>= 1) mc = max(mc, (uint32_t)__shfl_xor((int)mc, off, 64));
                     d_prim_it += mc;
                 }
                 if (leaf) {
-                    const uint32_t enc = ~(uint32_t)node;
+                    const bool from_pend = pend != 0;                    // the postponed leaf first
+                    const uint32_t enc = ~(uint32_t)(from_pend ? pend : node);
                     const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
                     for (uint32_t i = 0; i < cnt; i++) {
                         const uint32_t ps = first + i;
@@ -716,10 +731,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                         else hit_test<false>(S, ps, o, d, excl, t_min, t_max, b_index, b_slot);
                     }
                     if (COUNT) c_prims += cnt;
+                    if (from_pend) pend = 0;
+                    else if (sp > 0) { sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl]; }
+                    else node = kNoNode;
                     bool done = false;
                     if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
-                    else if (sp > 0) { sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl]; }
-                    else done = true;
+                    else if (node == kNoNode && pend == 0) done = true;
                     if (done) {
                         if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
                         else g_hit[slot] = float2{t_max, bits_f(b_slot)};
@@ -771,9 +788,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     } else if (sp > 0) {
                         sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
                     } else {
-                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
-                        active = false;
+                        node = kNoNode;                                  // nothing left to walk ...
+                        if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
+                            if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                            else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                            active = false;
+                        }
                     }
 #undef CRT_PUSH
                 } else if (inner) {
@@ -839,9 +859,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     } else if (sp > 0) {
                         sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
                     } else {
-                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
-                        active = false;
+                        node = kNoNode;                                  // nothing left to walk ...
+                        if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
+                            if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                            else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                            active = false;
+                        }
                     }
 #else
                     const float4 *np = nodes + 4 * (size_t)node;
@@ -874,10 +897,12 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     } else if (sp > 0) {
                         sp--; node = stk[sp * 64];
                     } else {
-                        // stack empty: this ray is finished
-                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
-                        active = false;
+                        node = kNoNode;                                  // stack empty ...
+                        if (pend == 0) {                                 // ... and no postponed leaf: this ray is finished
+                            if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
+                            else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                            active = false;
+                        }
                     }
 #endif
                 }

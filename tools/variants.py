@@ -17,7 +17,7 @@ for wpc in (14,):
 print(' | '.join(out))
 '''
 libs = [None] + sorted(glob.glob('tune_*.so'))
-for rnd in range(4):
+for rnd in range(2):
     for lib in libs:
         env = dict(os.environ)
         if lib: env['CRT_LIB'] = os.path.abspath(lib)
