@@ -26,6 +26,7 @@ hipError_t launch_debug_intersect(const DevScene &S, const float *rays, size_t n
                                   hipStream_t stream);
 hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
 hipError_t wf_launch_init(const WfParams &P, hipStream_t s);
+hipError_t wf_launch_tea(const WfParams &P, uint32_t *out, hipStream_t s);
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
 hipError_t wf_launch_finish(const WfParams &P, uint32_t max_paths, hipStream_t s);
@@ -133,7 +134,7 @@ struct crt_ctx {
     DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing];
     DevBuf<uint4> w_rng, w_misc;
     DevBuf<float2> w_hit;
-    DevBuf<uint32_t> w_vis, w_list_ext;
+    DevBuf<uint32_t> w_vis, w_list_ext, w_tea;
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
@@ -410,6 +411,7 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
     }
     for (uint32_t b = 0; b < kWfRing; b++)
         if (c->w_staging[b].n < staging_elems) HIPCHK(c, c->w_staging[b].alloc(staging_elems));
+    if (c->w_tea.n < (size_t)c->tw * c->th) HIPCHK(c, c->w_tea.alloc((size_t)c->tw * c->th));
     if (!c->w_wq.p) {
         HIPCHK(c, c->w_wq.alloc(kWfRing));
         HIPCHK(c, hipMemset(c->w_wq.p, 0, kWfRing * sizeof(WfWorkQ)));
@@ -875,6 +877,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.seg_n = 1;
             W.n_samples = n;
             W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
+            W.tea = c->w_tea.p;
             W.count = c->counting ? 1u : 0u;
             W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
             W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * 64u;
@@ -894,6 +897,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         // The context's stream is the control stream: it resets the work queue and forks the pipes (and,
         // later, finishes stragglers and resolves).  The pipes run on their own streams.
         HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
+        HIPCHK(c, wf_launch_tea(r.pipes[0].W, c->w_tea.p, c->stream));          // per-pixel RNG seed words of this tile
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         for (int p = 0; p < r.K; p++) {
             HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
@@ -992,7 +996,7 @@ void crt_destroy(crt_ctx *c)
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
-    c->w_vis.release(); c->w_list_ext.release(); c->w_wq.release();
+    c->w_vis.release(); c->w_list_ext.release(); c->w_tea.release(); c->w_wq.release();
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
         c->w_ctl[p].release();
         for (int b = 0; b < 2; b++) {

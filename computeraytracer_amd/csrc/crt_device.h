@@ -149,6 +149,7 @@ struct WfParams {
     uint32_t n_samples;              // k_wf_resolve: samples of the batch to resolve
     float4 *accum;
     uchar4 *rgba;
+    const uint32_t *tea;             // per tile pixel: tea(px, py*100), the 16-round seed of the pixel's RNG (:98), computed once
     uint32_t count;                  // 1: maintain ctl->counters
     int *stack_overflow;             // [level - kWfStack][global lane], for stacks deeper than the LDS part
     uint32_t overflow_lanes;

@@ -369,7 +369,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                 if (lx < P.tw && ly < P.th) {
                     const uint32_t px = P.x0 + lx, sample = P.seg[sg].first_sample + sample_off;
                     const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
-                    R.rng = Rng{py, px * 100u, sample, tea(px, py * 100u)};                  // :98
+                    R.rng = Rng{py, px * 100u, sample, P.tea[(size_t)ly * P.tw + lx]};       // :98 (tea(px, py*100) from k_wf_tea)
                     float jx = rnd(R.rng);
                     float fs = ((float)px + ((float)(sample % kGrid) + jx) / (float)kGrid) / (float)S.W;
                     float jy = rnd(R.rng);
@@ -1008,6 +1008,18 @@ __global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t l
     if (P.n_samples > 0) P.rgba[pix] = tonemap_rgba8(acc, (float)last_sample);
 }
 
+// The pixel's RNG seed word tea(px, py*100) (:98) depends on the pixel only: 16 rounds computed once per run
+// instead of at every re-arm (where every wave paid for them with a third of its lanes on).
+__global__ __launch_bounds__(256) void k_wf_tea(const WfParams P, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= P.tw * P.th) return;
+    const uint32_t lx = i % P.tw, ly = i / P.tw;
+    const uint32_t px = P.x0 + lx;
+    const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
+    out[i] = tea(px, py * 100u);
+}
+
 __global__ void k_wf_init(const WfParams P)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -1028,6 +1040,14 @@ __global__ void k_wf_init(const WfParams P)
 hipError_t wf_launch_init(const WfParams &P, hipStream_t s)
 {
     hipLaunchKernelGGL(k_wf_init, dim3(P.keep_pool ? 1u : (P.P + 255) / 256), dim3(256), 0, s, P);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_tea(const WfParams &P, uint32_t *out, hipStream_t s)
+{
+    const size_t npix = (size_t)P.tw * P.th;
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_wf_tea, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, P, out);
     return hipGetLastError();
 }
 
