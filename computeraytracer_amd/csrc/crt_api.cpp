@@ -129,7 +129,7 @@ struct crt_ctx {
     // wavefront pipeline (crt_wavefront.hip)
     int pipeline = 1;               // 1 = wavefront (default), 0 = v1 megakernel
     uint32_t wf_pool = 0;           // 0 = auto
-    uint32_t wf_waves_per_cu = 14;  // per pipe
+    uint32_t wf_waves_per_cu = 16;  // per pipe
     int num_cu = 0;
     DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing];
     DevBuf<uint4> w_rng, w_misc;

@@ -51,7 +51,7 @@ namespace crt {
 #define CRT_WF_SPEC 1
 #endif
 #ifndef CRT_WF_SHADE_BLOCK
-#define CRT_WF_SHADE_BLOCK 256
+#define CRT_WF_SHADE_BLOCK 64
 #endif
 #ifndef CRT_WF_SHADE_MIN_WAVES
 #define CRT_WF_SHADE_MIN_WAVES 1
