@@ -992,10 +992,12 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P)
 }
 
 // ------------------------------------------------------------------ resolve
-__global__ __launch_bounds__(256) void k_wf_resolve(const WfParams P, uint32_t last_sample)
+// (one-wave blocks: it runs on the control stream next to the pipes' kernels, and the next batch's queue reset
+// is queued behind it -- a block of several waves would wait for as many free slots on one CU)
+__global__ __launch_bounds__(64) void k_wf_resolve(const WfParams P, uint32_t last_sample)
 {
     const size_t npix = (size_t)P.tw * P.th;
-    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t pix = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (pix >= npix) return;
     const float4 a4 = P.accum[pix];
     f3 acc = f3{a4.x, a4.y, a4.z};
@@ -1090,7 +1092,7 @@ hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_
 {
     const size_t npix = (size_t)P.tw * P.th;
     if (npix == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, P, last_sample);
+    hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)((npix + 63) / 64)), dim3(64), 0, s, P, last_sample);
     return hipGetLastError();
 }
 
