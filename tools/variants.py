@@ -6,7 +6,7 @@ import sys, time; sys.path.insert(0,'.')
 from computeraytracer_amd import Renderer, scenes_synth
 ps = scenes_synth.atrium250k(1920,1080); r = Renderer(0); r.upload(ps).build_accel('bvh2')
 out = []
-for wpc in (16, 20):
+for wpc in (16,):
     r.set_option('wf_waves_per_cu', wpc)
     best = 1e9
     for _ in range(2):
