@@ -63,6 +63,10 @@ HostPrim read_prim(const uint8_t *base, size_t i)
 
 struct WfRun;
 int wf_flush(struct ::crt_ctx *c);
+int wf_check_dropped(struct ::crt_ctx *c);
+
+// Test hook (option "debug_fail_alloc" = k): the k-th device allocation from now on reports out-of-memory.
+long long g_fail_alloc_in = 0;
 
 template <typename T>
 struct DevBuf {
@@ -70,9 +74,12 @@ struct DevBuf {
     size_t n = 0;
     hipError_t alloc(size_t count) {
         release();
-        n = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void **)&p, count * sizeof(T));
+        const bool inject = g_fail_alloc_in > 0 && --g_fail_alloc_in == 0;
+        const hipError_t e = inject ? hipErrorOutOfMemory : hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }   // n stays 0: a later "is it large enough" test re-allocates
+        n = count;
+        return hipSuccess;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
@@ -151,6 +158,7 @@ struct crt_ctx {
     DevBuf<WfWorkQ> w_wq;
     WfWorkQ *h_wq[kMaxPipes][2] = {};                      // pinned: each pipe's snapshots of the two work queues
     WfCtl *h_ctl[kMaxPipes][2] = {};                       // pinned, double-buffered status readbacks
+    uint32_t *h_dropped = nullptr;                         // pinned [kMaxPipes]: WfCtl::dropped after the last flush
     hipEvent_t ev_ctl[kMaxPipes][2] = {};
     hipStream_t pipe_stream[kMaxPipes] = {};               // the pipes' own streams (the context's stream only forks and resolves)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {}, ev_evict[kMaxPipes] = {};
@@ -403,12 +411,17 @@ int upload_geometry(crt_ctx *c, int mode)
 int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
 {
     if (c->w_list_ext.n < list_elems) HIPCHK(c, c->w_list_ext.alloc(list_elems));
-    if (c->w_misc.n < P) {
-        HIPCHK(c, c->w_ray_o.alloc(P)); HIPCHK(c, c->w_ray_d.alloc(P)); HIPCHK(c, c->w_sh_d.alloc(P));
-        HIPCHK(c, c->w_beta.alloc(P)); HIPCHK(c, c->w_radiance.alloc(P)); HIPCHK(c, c->w_nee.alloc(P));
-        HIPCHK(c, c->w_rng.alloc(P)); HIPCHK(c, c->w_misc.alloc(P)); HIPCHK(c, c->w_hit.alloc(P));
-        HIPCHK(c, c->w_vis.alloc(P));
-    }
+    // (each array on its own: after a failed allocation that array reports n == 0 and is retried by the next call)
+    if (c->w_ray_o.n < P) HIPCHK(c, c->w_ray_o.alloc(P));
+    if (c->w_ray_d.n < P) HIPCHK(c, c->w_ray_d.alloc(P));
+    if (c->w_sh_d.n < P) HIPCHK(c, c->w_sh_d.alloc(P));
+    if (c->w_beta.n < P) HIPCHK(c, c->w_beta.alloc(P));
+    if (c->w_radiance.n < P) HIPCHK(c, c->w_radiance.alloc(P));
+    if (c->w_nee.n < P) HIPCHK(c, c->w_nee.alloc(P));
+    if (c->w_rng.n < P) HIPCHK(c, c->w_rng.alloc(P));
+    if (c->w_misc.n < P) HIPCHK(c, c->w_misc.alloc(P));
+    if (c->w_hit.n < P) HIPCHK(c, c->w_hit.alloc(P));
+    if (c->w_vis.n < P) HIPCHK(c, c->w_vis.alloc(P));
     for (uint32_t b = 0; b < kWfRing; b++)
         if (c->w_staging[b].n < staging_elems) HIPCHK(c, c->w_staging[b].alloc(staging_elems));
     if (c->w_tea.n < (size_t)c->tw * c->th) HIPCHK(c, c->w_tea.alloc((size_t)c->tw * c->th));
@@ -416,6 +429,8 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
         HIPCHK(c, c->w_wq.alloc(kWfRing));
         HIPCHK(c, hipMemset(c->w_wq.p, 0, kWfRing * sizeof(WfWorkQ)));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_dropped, crt_ctx::kMaxPipes * sizeof(uint32_t), hipHostMallocDefault));
+        std::memset(c->h_dropped, 0, crt_ctx::kMaxPipes * sizeof(uint32_t));
         for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
             HIPCHK(c, c->w_ctl[p].alloc(1));
             HIPCHK(c, hipMemset(c->w_ctl[p].p, 0, sizeof(WfCtl)));
@@ -689,6 +704,7 @@ int wf_drive(crt_ctx *c, bool to_end)
                 wf_set_queues(c);
             }
             const WfCtl *hc = c->h_ctl[p][pp.cur];
+            if (hc->dropped) return fail(c, CRT_EDEVICE, "wavefront pipeline: a capacity guard dropped %u paths (pipe %d)", hc->dropped, p);
             unsigned long long rays = 0, old = 0;
             uint32_t bound = 0;
             for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
@@ -798,6 +814,9 @@ int wf_drive(crt_ctx *c, bool to_end)
         }
     }
     if (to_end || empty) {
+        // (checked by wf_check_dropped after the caller's stream synchronisation)
+        for (int p = 0; p < K; p++)
+            HIPCHK(c, hipMemcpyAsync(&c->h_dropped[p], &c->w_ctl[p].p->dropped, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         // the pool is empty; the next batch sets the pipes up afresh (after everything enqueued here)
         for (int p = 0; p < K; p++) {
             HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
@@ -805,6 +824,19 @@ int wf_drive(crt_ctx *c, bool to_end)
         }
         r.live = false;
     }
+    return CRT_OK;
+}
+
+// After a flush and a synchronisation of the context's stream: did a device-side capacity guard drop a path?
+int wf_check_dropped(crt_ctx *c)
+{
+    if (!c->h_dropped) return CRT_OK;
+    for (int p = 0; p < crt_ctx::kMaxPipes; p++)
+        if (c->h_dropped[p]) {
+            const uint32_t n = c->h_dropped[p];
+            c->h_dropped[p] = 0;
+            return fail(c, CRT_EDEVICE, "wavefront pipeline: a capacity guard dropped %u paths (pipe %d); the frame is incomplete", n, p);
+        }
     return CRT_OK;
 }
 
@@ -1010,6 +1042,7 @@ void crt_destroy(crt_ctx *c)
     for (int p = 0; p < crt_ctx::kMaxPipes; p++)
         for (int b = 0; b < 2; b++) if (c->h_wq[p][b]) (void)hipHostFree(c->h_wq[p][b]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->h_dropped) (void)hipHostFree(c->h_dropped);
 
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1049,6 +1082,9 @@ int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const voi
         lts[i] = read_prim((const uint8_t *)lights, i);
         if (lts[i].emission >= nspectra) return fail(c, CRT_EINVAL, "light %zu: emission index out of range", i);
     }
+    // from here on the old scene is gone: a failure below must not leave a context that can still trace
+    c->have_scene = false;
+    c->accel_mode = -1;
     c->prims.swap(prims);
     c->lights.swap(lts);
     std::memcpy(c->camera, camera, sizeof c->camera);
@@ -1080,14 +1116,14 @@ int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const voi
     HIPCHK(c, hipMemcpy(c->d_lights.p, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
     S.spectra = c->d_spectra.p; S.cie = c->d_cie.p; S.lights = c->d_lights.p;
 
-    c->have_scene = true;
-    c->accel_mode = -1;
     c->x0 = 0; c->y0 = 0; c->tw = c->W; c->th = c->H;
     c->band = 0x40000000u; c->stride = 1; c->phase = 0;
     c->accum_bound = nullptr; c->rgba_bound = nullptr;
+    c->have_scene = true;                                        // (alloc_tile / zero_state below need it for the error paths of others)
     int rc = alloc_tile(c);
-    if (rc) return rc;
-    return zero_state(c);
+    if (rc == CRT_OK) rc = zero_state(c);
+    if (rc) c->have_scene = false;
+    return rc;
 }
 
 int crt_set_tile(crt_ctx *c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
@@ -1155,6 +1191,8 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_trace: upload a scene first");
     if (c->accel_mode < 0) return fail(c, CRT_ESTATE, "crt_trace: call crt_build_accel first");
     HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)c->tw * c->th != 0 && (!accum_ptr(c) || !rgba_ptr(c)))
+        return fail(c, CRT_ENOMEM, "crt_trace: the tile's output buffers are not allocated (an earlier crt_set_tile / crt_set_row_bands failed)");
     TraceParams P{};
     P.sc = c->sc;
     P.x0 = c->x0; P.y0 = c->y0; P.tw = c->tw; P.th = c->th;
@@ -1201,7 +1239,7 @@ int crt_sync(crt_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return CRT_OK;
+    return wf_check_dropped(c);
 }
 
 int crt_sample_count(crt_ctx *c, uint32_t *out)
@@ -1227,7 +1265,7 @@ int crt_read_accum(crt_ctx *c, float *out)
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(out, accum_ptr(c), n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return CRT_OK;
+    return wf_check_dropped(c);
 }
 
 int crt_read_rgba8(crt_ctx *c, uint8_t *out)
@@ -1239,7 +1277,7 @@ int crt_read_rgba8(crt_ctx *c, uint8_t *out)
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(out, rgba_ptr(c), n * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return CRT_OK;
+    return wf_check_dropped(c);
 }
 
 int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
@@ -1382,6 +1420,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return CRT_EINVAL;
     { int rc_ = wf_flush(c); if (rc_) return rc_; }
+    if (!std::strcmp(name, "debug_fail_alloc")) { g_fail_alloc_in = value; return CRT_OK; }
     if (!std::strcmp(name, "wf_defer")) { c->wf_defer = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "spp_per_launch")) { c->spp_per_launch = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "pipeline")) { c->pipeline = value ? 1 : 0; return CRT_OK; }

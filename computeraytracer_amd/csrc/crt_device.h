@@ -102,6 +102,8 @@ struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
     unsigned long long counters[CRT_NCOUNTERS_DEV];
     uint32_t side_count[kWfRing];    // paths moved to the side pool, per batch id
+    uint32_t dropped;                // paths a capacity guard had to leave behind (side pool full, bounce guard of
+                                     // k_wf_finish): must stay 0 -- the host turns anything else into CRT_EDEVICE
 };
 // The work queue is shared by the pipes of a context (two half-pools run on two streams so that
 // one half's streaming shade pass overlaps the other half's latency-bound traversal).  There are kWfRing

@@ -72,9 +72,9 @@ __device__ __forceinline__ uint32_t prefix_popc(unsigned long long mask, uint32_
 
 // The reference's own loop (:503-518) for a non-finite ray, out of line and taking only
 // values (a by-reference scene would force the kernel-argument struct into scratch).
-__device__ __noinline__ void resolve_nonfinite(const float4 *prim, const float4 *primD, const uint32_t *slot_of_index,
-                                               uint32_t nprim, float hit_pad, float ox, float oy, float oz, float dx,
-                                               float dy, float dz, uint32_t exclude, float2 *out)
+__device__ __noinline__ float2 resolve_nonfinite(const float4 *prim, const float4 *primD, const uint32_t *slot_of_index,
+                                                 uint32_t nprim, float hit_pad, float ox, float oy, float oz, float dx,
+                                                 float dy, float dz, uint32_t exclude)
 {
     DevScene S{};
     S.prim = prim; S.primD = primD; S.slot_of_index = slot_of_index; S.nprim = nprim; S.hit_pad = hit_pad;
@@ -82,7 +82,7 @@ __device__ __noinline__ void resolve_nonfinite(const float4 *prim, const float4 
     uint32_t bi = kNoHit, bs = kNoHit;
     const f3 o = f3{ox, oy, oz}, d = f3{dx, dy, dz};
     for (uint32_t i = 0; i < nprim; i++) hit_test<true>(S, slot_of_index[i], o, d, exclude, 0.001f, tm, bi, bs);
-    *out = float2{tm, bits_f(bs)};
+    return float2{tm, bits_f(bs)};
 }
 
 // ------------------------------------------------------------------ shade
@@ -98,6 +98,21 @@ __device__ __forceinline__ void wavelengths_of(uint32_t lambda, uint32_t wl[4])
 {
     wl[0] = lambda; wl[1] = (lambda + 4u) % kNLambda; wl[2] = (lambda + 8u) % kNLambda;
     wl[3] = (lambda + 12u) % kNLambda;                           // :321
+}
+
+// compute_light_radiance's tail (:388-400) for a light primitive hit at t_l along the shadow ray: the NEE term before
+// the caller's BRDF * beta (:187).
+__device__ __forceinline__ f4 nee_term(const DevScene &S, uint32_t l_slot, f3 pos, f3 ldir, float t_l, float cos_theta,
+                                       uint32_t light_emission, const uint32_t wl[4])
+{
+    f3 lp, ln; uint32_t lmeta;
+    hit_attributes(S, l_slot, pos, ldir, t_l, lp, ln, lmeta);
+    f4 spec = sample_spectrum(S, light_emission, wl);
+    f4 le = spec * cos_theta;
+    float pdf_l = compute_light_pdf(S, (lmeta >> 4) & 0x3FFFu, lp, ln, pos, ldir);
+    float pdf_b = cos_theta / CRT_PI;
+    float weight_l = power_heuristic(1.0f, pdf_l, 1.0f, pdf_b);
+    return (le * weight_l) / pdf_l;
 }
 
 struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary, old; };
@@ -209,7 +224,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                         // shadow_intersect (:697-705): the light's own primitive first
                         float t_l = CRT_INFINITY;
                         uint32_t l_index = kNoHit, l_slot = kNoHit;
-                        if (include < S.nprim && finite3(ldir)) {
+                        const bool sh_finite = finite3(ldir) && finite3(pos);
+                        if (include < S.nprim && sh_finite) {
                             hit_test<false>(S, S.slot_of_index[include], pos, ldir, b_index, 0.001f, t_l, l_index, l_slot);
                             if (COUNT) cn.prims++;
                         }
@@ -217,16 +233,24 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                         // NEE term (:400) is exactly +0 whatever the visibility -- adding it changes nothing, and
                         // the shadow ray need not be walked (weight and pdf are finite: abs_cos >= 1e-5, :366).
                         const float cos_theta = max_(0.0f, dot(nrm, ldir));
-                        if (l_slot != kNoHit && cos_theta > 0.0f) {
-                            f3 lp, ln; uint32_t lmeta;
-                            hit_attributes(S, l_slot, pos, ldir, t_l, lp, ln, lmeta);
+                        if (!sh_finite) {
+                            // A non-finite shadow ray (the light sample coincides with the hit point, or a light record
+                            // with non-finite coordinates): the reference's loop decides in its own order -- a NaN passes
+                            // every reject-form test (:546,:557,:566,:605,:609), so the last patch / sphere that is not
+                            // excluded is "the closest hit" -- and the NEE term (NaN then) is added right here when that
+                            // is the light (:700, :393-400); the single-kernel form takes the same route.
+                            const float2 rr = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, pos.x, pos.y, pos.z,
+                                                                ldir.x, ldir.y, ldir.z, b_index);
+                            const uint32_t w_slot = f_bits(rr.y);
+                            if (COUNT) cn.prims += S.nprim;
+                            if (w_slot != kNoHit && f_bits(S.prim[3 * (size_t)w_slot + 1].w) == include) {
+                                if (COUNT) cn.hits++;
+                                const f4 nee = nee_term(S, w_slot, pos, ldir, rr.x, cos_theta, f_bits(L0.w), wl);
+                                R.radiance = R.radiance + (brdf * nee) * R.beta;
+                            }
+                        } else if (l_slot != kNoHit && cos_theta > 0.0f) {
                             if (COUNT) cn.hits++;
-                            f4 spec = sample_spectrum(S, f_bits(L0.w), wl);
-                            f4 le = spec * cos_theta;
-                            float pdf_l = compute_light_pdf(S, (lmeta >> 4) & 0x3FFFu, lp, ln, pos, ldir);
-                            float pdf_b = cos_theta / CRT_PI;
-                            float weight_l = power_heuristic(1.0f, pdf_l, 1.0f, pdf_b);
-                            f4 nee = (le * weight_l) / pdf_l;
+                            const f4 nee = nee_term(S, l_slot, pos, ldir, t_l, cos_theta, f_bits(L0.w), wl);
                             f4 c = (brdf * nee) * R.beta;          // added to radiance iff the light is visible
                             P.nee[slot] = float4{c.x, c.y, c.z, c.w};
                             P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};
@@ -236,8 +260,6 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                             R.flags |= kWfShadow;
                             if (COUNT) cn.walk++;
                         }
-                        // non-finite light direction: the reference loop decides (never seen in practice;
-                        // handled by tracing it as a brute-force ray in the mega kernel) -> treated as blocked
                         f3 new_direction = cosine_hemisphere(R.rng, nrm, R.last_pdf);
                         float cos_theta2 = abs_(dot(nrm, new_direction));
                         R.beta = R.beta * ((brdf * cos_theta2) / R.last_pdf);
@@ -408,8 +430,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             // so the traversal kernel stays free of the fallback.
             uint32_t resolved = 0u;
             if (emit_ext && (!finite3(R.ray_o) || !finite3(R.ray_d))) {
-                resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, R.ray_o.x, R.ray_o.y, R.ray_o.z,
-                                  R.ray_d.x, R.ray_d.y, R.ray_d.z, R.exclude, &P.hit[slot]);
+                P.hit[slot] = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, R.ray_o.x, R.ray_o.y, R.ray_o.z,
+                                                R.ray_d.x, R.ray_d.y, R.ray_d.z, R.exclude);
                 if (COUNT) cn.prims += S.nprim;
                 resolved = 1u;
             }
@@ -477,6 +499,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
             if (lane_id() == 0) base = atomicAdd(&ctl->side_count[b], (uint32_t)__popcll(m));
             base = __shfl(base, 0, 64);
             const uint32_t idx = base + prefix_popc(m, lane_id());
+            if (go && par == b && idx >= kWfSideCap) atomicAdd(&ctl->dropped, 1u);   // must not happen: the host checks
             if (go && par == b && idx < kWfSideCap) {            // (the host asks only when everything fits)
                 const uint32_t d = P.side_base[b] + idx;
                 P.ray_o[d] = P.ray_o[slot]; P.ray_d[d] = P.ray_d[slot]; P.sh_d[d] = P.sh_d[slot]; P.beta[d] = P.beta[slot];
@@ -979,6 +1002,8 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P)
             alive = so.alive; pend_ext = so.emit_ext; pend_sh = so.emit_sh;
         }
     }
+    if (alive) atomicAdd(&ctl->dropped, 1u);     // the bounce guard ended a live path (cannot happen: MAXDEPTH is 100): reported
+
     if (COUNT) {
         wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
         wave_add(ctl->counters + CRT_CNT_BOUNCES, cn.bounces);
@@ -1030,7 +1055,7 @@ __global__ void k_wf_init(const WfParams P)
         WfCtl *c = P.ctl;
         if (!P.keep_pool)
             for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
-        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; }
+        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else { for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; c->dropped = 0; } }
         if (P.reset_wq) {
             P.wq[P.batch_id].work[i].cur = 0;
             if (i == 0) P.wq[P.batch_id].work_done = 0;

@@ -485,6 +485,11 @@ def test_gpu_lbvh_build_gives_the_same_image(renderer, orc):
     a2, r2 = render(renderer, big, 2, "lbvh", tile)
     assert renderer.accel_stats()["leaves"] == len(big.primitives)
     assert np.array_equal(bits(a1), bits(a2)) and np.array_equal(r1, r2)
+    # ... and the oracle's (the reference loop on the CPU) on a crop of that window
+    rect = (940, 600, 972, 616)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(big).render(2, rect=rect)
+    cx0, cy0 = rect[0] - tile[0], rect[1] - tile[1]
+    assert_same_image(a2[cy0:cy0 + 16, cx0:cx0 + 32], r2[cy0:cy0 + 16, cx0:cx0 + 32], acc_o, rgba_o, rect)
     # ray level, against the reference loop on the GPU
     rng = np.random.default_rng(5)
     o = rng.uniform(-1.0, 1.0, (20000, 3)).astype(np.float32) * np.float32(2.0)
@@ -530,6 +535,169 @@ def test_mesh_scene_and_python_cli(renderer, orc, tmp_path):
     d = np.load(ck)
     assert int(d["sample"]) == 6 and np.array_equal(bits(d["accum"]), bits(acc))
     assert (tmp_path / "o.png").read_bytes()[:4] == b"\x89PNG"
+
+
+# ------------------------------------------------------------------ BASELINE configs 4 and 5 at their real sizes
+def test_c4_4k_row_band_share_vs_oracle(renderer, orc):
+    """BASELINE config 4: S2 at 3840 x 2160, the frame dealt to 8 GPUs in bands of 8 rows.  The full 4K frame
+    equals the oracle on three crops, and a rank's share (crt_set_row_bands(8, 8, k)) equals those rows of it."""
+    from computeraytracer_amd.partition import band_rows
+    from computeraytracer_amd.scenes_synth import atrium250k
+    ps = atrium250k(3840, 2160)
+    full_acc, full_rgba = render(renderer, ps, 2)
+    assert full_acc.shape == (2160, 3840, 4)
+    sc = orc.Scene.from_packed(ps)
+    for rect in [(1880, 1200, 1912, 1216), (1400, 800, 1432, 816), (2200, 1640, 2232, 1656)]:
+        acc_o, rgba_o, _ = sc.render(2, rect=rect)
+        x0, y0, x1, y1 = rect
+        assert_same_image(full_acc[y0:y1, x0:x1], full_rgba[y0:y1, x0:x1], acc_o, rgba_o, rect)
+    for part in (0, 3, 7):
+        rows = band_rows(2160, 8, part, 8)
+        renderer.set_row_bands(8, 8, part)
+        renderer.frame(2).sync()
+        acc, rgba = renderer.read_accum(), renderer.read_rgba8()
+        assert acc.shape == (len(rows), 3840, 4) and len(rows) in (264, 272)
+        assert np.array_equal(bits(acc), bits(full_acc[rows])) and np.array_equal(rgba, full_rgba[rows])
+    renderer.set_tile(0, 0, 3840, 2160)
+
+
+def test_c5_soup_10M_triangles_full_size(renderer, orc):
+    """BASELINE config 5 at its real size: 10 000 000 random triangles (a 1.4 GB tree, depth-28+ stacks, the leaf
+    encoding at 24-bit slot numbers), both builders.  Ray level: 20 000 random rays through the BVH == the reference
+    loop on the GPU, 200 of them == the oracle's loop.  Image level: a 16 x 16 crop at 1 spp == the oracle; a window
+    through the wavefront pipeline == the single-kernel form; a tile == the same pixels of the 1080p frame."""
+    from computeraytracer_amd.scenes_synth import soup
+    ps = soup(10_000_000, 1920, 1080)
+    assert len(ps.primitives) == 6 + 10_000_000
+    sc = orc.Scene.from_packed(ps)
+    rng = np.random.default_rng(11)
+    n = 20_000
+    o = rng.uniform(-20, 575, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    excl = np.full(n, MAXU, np.uint32)
+    excl[::5] = rng.integers(0, len(ps.primitives), len(excl[::5]))
+    crop = (952, 532, 968, 548)
+    acc_o, rgba_o, _ = sc.render(1, rect=crop)
+    window = (832, 476, 1088, 604)
+    renderer.upload(ps)
+    got = {}
+    for mode in ("bvh2", "lbvh"):
+        renderer.build_accel(mode)
+        st = renderer.accel_stats()
+        assert st["builder"] == ("sah-host" if mode == "bvh2" else "lbvh-gpu") and st["max_depth"] <= 62
+        got[mode] = renderer.debug_intersect(o, d, excl)
+        renderer.set_tile(*crop)
+        renderer.frame(1).sync()
+        assert_same_image(renderer.read_accum(), renderer.read_rgba8(), acc_o, rgba_o, crop)
+        renderer.set_tile(*window)
+        renderer.frame(1).sync()
+        got[mode + "_win"] = (renderer.read_accum(), renderer.read_rgba8())
+        renderer.set_tile(0, 0, 1920, 1080)
+    # (the GPU LBVH build is the last one built) whole frame: tile invariance, and the single-kernel form on the window
+    renderer.frame(1).sync()
+    full_acc, full_rgba = renderer.read_accum(), renderer.read_rgba8()
+    x0, y0, x1, y1 = window
+    for key in ("bvh2_win", "lbvh_win"):
+        assert np.array_equal(bits(got[key][0]), bits(full_acc[y0:y1, x0:x1])) and np.array_equal(got[key][1], full_rgba[y0:y1, x0:x1])
+    try:
+        renderer.set_option("pipeline", 0)
+        renderer.set_tile(*window)
+        renderer.frame(1).sync()
+        assert np.array_equal(bits(renderer.read_accum()), bits(full_acc[y0:y1, x0:x1]))
+    finally:
+        renderer.set_option("pipeline", 1)
+        renderer.set_tile(0, 0, 1920, 1080)
+    renderer.build_accel("none")
+    brute = renderer.debug_intersect(o, d, excl)
+    hit = brute[:, 7].view(np.uint32) != MAXU
+    assert 0.5 < hit.mean() <= 1.0
+    for mode in ("bvh2", "lbvh"):
+        assert np.array_equal(got[mode][:, 7].view(np.uint32), brute[:, 7].view(np.uint32))
+        assert np.array_equal(bits(got[mode][hit]), bits(brute[hit]))
+    for i in range(0, n, 100):
+        of, ou = sc.intersect(o[i], d[i], int(excl[i]))
+        gi = int(brute[i, 7:8].view(np.uint32)[0])
+        assert gi == (int(ou[1]) if ou[0] else MAXU)
+        if ou[0]:
+            assert np.array_equal(bits(brute[i, :7]), bits(of))
+
+
+# ------------------------------------------------------------------ non-finite shadow rays
+def _nan_light_scene(w, h, light_last):
+    """Cornell's patches (no spheres) with the light record's origin at +inf: every light sample gives a NaN light
+    direction.  Under the reference's reject-form tests (ComputeShader.wgsl:546,557,566) a NaN ray passes every test
+    of every patch, so "the closest hit" of shadow_intersect is the LAST patch of the array that is not excluded:
+    with light_last the light itself (NEE term = NaN, added), otherwise an ordinary wall (blocked)."""
+    from computeraytracer_amd import cornell, scene as S
+    c = cornell(w, h)
+    keep = np.flatnonzero(c.primitives["category"] == 0)
+    if light_last:
+        is_light = c.primitives["data4"][keep, 2] == 1
+        keep = np.concatenate([keep[~is_light], keep[is_light]])
+    prims = np.zeros(len(keep), S.PRIM_DTYPE)            # (indexing into a fresh array keeps the 80-byte stride)
+    prims[:] = c.primitives[keep]
+    prims["data4"][:, 3] = np.arange(len(prims))
+    src = S.lights_of(prims)
+    lights = np.zeros(len(src), S.PRIM_DTYPE)
+    lights[:] = src
+    lights["data1"][:, 0] = np.inf
+    return S.PackedScene(prims, lights, c.camera, c.spectra, c.cie)
+
+
+@pytest.mark.parametrize("light_last", [True, False])
+def test_non_finite_shadow_rays_follow_the_reference_loop(renderer, orc, light_last):
+    """One decision for every code path: the wavefront pipeline, the single-kernel form and the reference loop on
+    the GPU all give the oracle's image (NaN pixels where the oracle has NaN, bit-identical elsewhere)."""
+    ps = _nan_light_scene(96, 96, light_last)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(3)
+    nan_o = np.isnan(acc_o[..., :3]).any(-1)
+    assert nan_o.mean() > 0.5 if light_last else not nan_o.any()
+    try:
+        for pipeline, mode in [(1, "bvh2"), (0, "bvh2"), (1, "none"), (1, "lbvh")]:
+            renderer.set_option("pipeline", pipeline)
+            acc, rgba = render(renderer, ps, 3, mode)
+            nan_g = np.isnan(acc[..., :3]).any(-1)
+            assert np.array_equal(nan_g, nan_o), (pipeline, mode)
+            assert np.array_equal(bits(acc[~nan_o])[..., :3], bits(acc_o[~nan_o])[..., :3]), (pipeline, mode)
+            assert np.array_equal(rgba, rgba_o), (pipeline, mode)
+    finally:
+        renderer.set_option("pipeline", 1)
+
+
+def test_out_of_memory_is_reported_and_the_context_recovers(orc):
+    """A failed device allocation (injected: option debug_fail_alloc = k fails the k-th one) gives CRT_ENOMEM, never a
+    launch on a null pointer; the same context renders correctly afterwards."""
+    from computeraytracer_amd import Renderer, cornell
+    from computeraytracer_amd._lib import CrtError
+    ps = cornell(96, 64)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(2)
+    for k in (1, 3, 9, 12):                           # ray lists, pool arrays, staging buffers, ... of a fresh context
+        r = Renderer(0)
+        try:
+            r.upload(ps).build_accel("bvh2")
+            r.set_option("debug_fail_alloc", k)
+            with pytest.raises(CrtError) as e:
+                r.frame(2)
+            assert e.value.code == -4, str(e.value)
+            r.frame(2).sync()
+            assert_same_image(r.read_accum(), r.read_rgba8(), acc_o, rgba_o)
+        finally:
+            r.set_option("debug_fail_alloc", 0)
+            r.close()
+    r = Renderer(0)
+    try:
+        r.set_option("debug_fail_alloc", 1)           # ... and while a scene is being uploaded
+        with pytest.raises(CrtError):
+            r.upload(ps)
+        with pytest.raises(CrtError, match="upload a scene first"):
+            r.frame(1)
+        r.set_option("debug_fail_alloc", 0)
+        r.upload(ps).build_accel("bvh2").frame(2).sync()
+        assert_same_image(r.read_accum(), r.read_rgba8(), acc_o, rgba_o)
+    finally:
+        r.set_option("debug_fail_alloc", 0)
+        r.close()
 
 
 # ------------------------------------------------------------------ error behaviour
