@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/crt.h"
@@ -29,7 +30,7 @@ hipError_t wf_launch_init(const WfParams &P, hipStream_t s);
 hipError_t wf_launch_tea(const WfParams &P, uint32_t *out, hipStream_t s);
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
-hipError_t wf_launch_finish(const WfParams &P, uint32_t max_paths, hipStream_t s);
+hipError_t wf_launch_finish(const WfParams &P, WfFinishSegs G, uint32_t max_paths, hipStream_t s);
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
 hipError_t build_lbvh(const float *lo, const float *hi, uint32_t n, Bvh &out, hipStream_t stream);
 }  // namespace crt
@@ -145,23 +146,30 @@ struct crt_ctx {
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
-    int wf_defer = 1;               // 1: a batch ends parked, its last paths finish under the next batch (or at crt_sync)
+    int wf_defer = 1;               // 1: crt_trace returns with its batch in flight; its paths finish under the next batches (or at crt_sync)
     int wf_tail_walk = 1;           // shade walks the ray lists once few paths are left
-    int wf_park_its = 4;            // a batch parks when its queue holds less than this many iterations' worth
-    int wf_chunk = 2;               // iterations enqueued per status readback (the host's decisions lag by two chunks)
-    int wf_ring = 4;                // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
+    int wf_chunk = 1;               // iterations per status record at most
+    int wf_ahead = 3;               // iterations in flight per pipe before the pump waits for a status
+    int wf_ring = 32;               // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
+    int wf_pool_spp = 2;            // automatic pool size: at least this many path slots per tile pixel (within 1 M .. 8 M)
+    double wf_feed = 1.0;           // pump: weight of the work the iterations in flight are expected to consume
     WfRun *run = nullptr;           // pipeline state between calls
     uint32_t wf_finish_at = 32768;  // paths of the oldest batch left (per pipe) at which they move to the side pool; 0 = never
     uint32_t wf_flush_at = 4096;    // the same for the LAST batch at crt_sync (nothing to hide its tail under); 0 = never
     uint32_t wf_side_ppw = 64, wf_flush_ppw = 4;   // k_wf_finish: paths per wave, under the next batch / at crt_sync
     DevBuf<WfCtl> w_ctl[kMaxPipes];
     DevBuf<WfWorkQ> w_wq;
-    WfWorkQ *h_wq[kMaxPipes][2] = {};                      // pinned: each pipe's snapshots of the two work queues
-    WfCtl *h_ctl[kMaxPipes][2] = {};                       // pinned, double-buffered status readbacks
+    static constexpr int kStatusSlots = 64;                // status records per pipe (one per iteration in flight)
+    WfStatus *h_status[kMaxPipes] = {};                    // pinned host records, written by k_wf_status ...
+    WfStatus *d_status[kMaxPipes] = {};                    // ... through these device pointers
+    hipEvent_t ev_status[kMaxPipes][kStatusSlots] = {};
     uint32_t *h_dropped = nullptr;                         // pinned [kMaxPipes]: WfCtl::dropped after the last flush
-    hipEvent_t ev_ctl[kMaxPipes][2] = {};
-    hipStream_t pipe_stream[kMaxPipes] = {};               // the pipes' own streams (the context's stream only forks and resolves)
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {}, ev_evict[kMaxPipes] = {};
+    bool wf_host_ready = false;                            // the streams / events / pinned buffers below exist
+    hipStream_t pipe_stream[kMaxPipes] = {};               // the pipes' own streams (the context's stream sets up, finishes stragglers and resolves)
+    hipStream_t pub_stream = nullptr;                      // publishes a new batch's queue (waits only for what it must)
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {}, ev_pub_join[kMaxPipes] = {};
+    hipEvent_t ev_evict[kMaxPipes][kWfRing] = {};          // after the shade launch of that pipe that evicts that batch id
+    hipEvent_t ev_resolved[kWfRing] = {};                  // after the resolve pass of the batch that used the id last
     bool time_kernels = false;
     std::vector<hipEvent_t> kev;    // event pairs around k_wf_trace launches
     float last_trace_kernel_ms = 0.0f;
@@ -408,7 +416,29 @@ int upload_geometry(crt_ctx *c, int mode)
 
 
 // ---------------------------------------------------------------- wavefront driver
-int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
+//
+// The pool (crt_wavefront.hip) is a steady-state machine: every iteration of a pipe is one shade launch (advance
+// every path slot by one bounce, re-arm dead slots from the work queues) and one traversal launch.  The host's
+// part is to keep it fed and to retire finished batches:
+//
+//   publish   a crt_trace call becomes a BATCH: a work queue, a staging buffer and side pools of its own, indexed by
+//             the batch id that a path carries in its flags.  Up to `ring` batches are in flight.
+//   pump      enqueue as many iterations as the published work needs -- by an estimate of how many work items one
+//             iteration consumes, corrected by every status that comes back -- and return.  The call does NOT wait
+//             for its work: statuses are polled (hipEventQuery), the only blocking waits are back-pressure (the
+//             ring of batches or of status buffers is full).  A loop of 1-spp calls (the reference's frame loop,
+//             main.js:597-611) therefore runs the pool exactly like one large batch does.
+//   retire    batches resolve in order (the accumulator is summed in sample order).  A batch whose queue is dry
+//             for every pipe and of which few paths are left has those EVICTED by the pipes' next shade launch into
+//             side pools; k_wf_finish runs them to their end (one launch for all pipes and every batch that is ready)
+//             and k_wf_resolve adds the batch to the accumulator -- on the context's stream, under the pool's work.
+//   flush     crt_sync and every call that reads or changes state: run everything to its end.
+//
+// After every chunk of iterations k_wf_status reduces what the driver needs (queue cursors, rays listed, paths alive
+// per batch) to one small record that is copied back asynchronously.
+constexpr int kStatusRing = crt_ctx::kStatusSlots;
+
+int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uint32_t ring)
 {
     if (c->w_list_ext.n < list_elems) HIPCHK(c, c->w_list_ext.alloc(list_elems));
     // (each array on its own: after a failed allocation that array reports n == 0 and is retried by the next call)
@@ -422,27 +452,41 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
     if (c->w_misc.n < P) HIPCHK(c, c->w_misc.alloc(P));
     if (c->w_hit.n < P) HIPCHK(c, c->w_hit.alloc(P));
     if (c->w_vis.n < P) HIPCHK(c, c->w_vis.alloc(P));
-    for (uint32_t b = 0; b < kWfRing; b++)
+    for (uint32_t b = 0; b < ring; b++)
         if (c->w_staging[b].n < staging_elems) HIPCHK(c, c->w_staging[b].alloc(staging_elems));
     if (c->w_tea.n < (size_t)c->tw * c->th) HIPCHK(c, c->w_tea.alloc((size_t)c->tw * c->th));
-    if (!c->w_wq.p) {
-        HIPCHK(c, c->w_wq.alloc(kWfRing));
-        HIPCHK(c, hipMemset(c->w_wq.p, 0, kWfRing * sizeof(WfWorkQ)));
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_dropped, crt_ctx::kMaxPipes * sizeof(uint32_t), hipHostMallocDefault));
-        std::memset(c->h_dropped, 0, crt_ctx::kMaxPipes * sizeof(uint32_t));
-        for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
-            HIPCHK(c, c->w_ctl[p].alloc(1));
-            HIPCHK(c, hipMemset(c->w_ctl[p].p, 0, sizeof(WfCtl)));
-            for (int b = 0; b < 2; b++) {
-                HIPCHK(c, hipHostMalloc((void **)&c->h_ctl[p][b], sizeof(WfCtl), hipHostMallocDefault));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_ctl[p][b], hipEventDisableTiming));
-            }
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[p], hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_evict[p], hipEventDisableTiming));
+    if (!c->wf_host_ready) {
+        if (!c->w_wq.p) {
+            HIPCHK(c, c->w_wq.alloc(kWfRing));
+            HIPCHK(c, hipMemset(c->w_wq.p, 0, kWfRing * sizeof(WfWorkQ)));
         }
-        for (int p = 0; p < crt_ctx::kMaxPipes; p++)
-            for (int b = 0; b < 2; b++) HIPCHK(c, hipHostMalloc((void **)&c->h_wq[p][b], kWfRing * sizeof(WfWorkQ), hipHostMallocDefault));
+        if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        if (!c->pub_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->pub_stream, hipStreamNonBlocking));
+        if (!c->h_dropped) {
+            HIPCHK(c, hipHostMalloc((void **)&c->h_dropped, crt_ctx::kMaxPipes * sizeof(uint32_t), hipHostMallocDefault));
+            std::memset(c->h_dropped, 0, crt_ctx::kMaxPipes * sizeof(uint32_t));
+        }
+        for (uint32_t b = 0; b < kWfRing; b++)
+            if (!c->ev_resolved[b]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_resolved[b], hipEventDisableTiming));
+        for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
+            if (!c->w_ctl[p].p) {
+                HIPCHK(c, c->w_ctl[p].alloc(1));
+                HIPCHK(c, hipMemset(c->w_ctl[p].p, 0, sizeof(WfCtl)));
+            }
+            if (!c->h_status[p]) {
+                // coherent pinned host memory that k_wf_status writes directly (no copy kernel behind every chunk)
+                HIPCHK(c, hipHostMalloc((void **)&c->h_status[p], kStatusRing * sizeof(WfStatus), hipHostMallocMapped | hipHostMallocCoherent));
+                std::memset(c->h_status[p], 0, kStatusRing * sizeof(WfStatus));
+                HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_status[p], c->h_status[p], 0));
+            }
+            for (int k = 0; k < kStatusRing; k++)
+                if (!c->ev_status[p][k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_status[p][k], hipEventDisableTiming));
+            if (!c->ev_join[p]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[p], hipEventDisableTiming));
+            if (!c->ev_pub_join[p]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pub_join[p], hipEventDisableTiming));
+            for (uint32_t b = 0; b < kWfRing; b++)
+                if (!c->ev_evict[p][b]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_evict[p][b], hipEventDisableTiming));
+        }
+        c->wf_host_ready = true;
     }
     if (c->num_cu == 0) {
         hipDeviceProp_t prop;
@@ -460,49 +504,52 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems)
 struct WfPipe {
     WfParams W{};
     hipStream_t stream = nullptr;
-    uint32_t it = 0, chunk = 2, tail_bound = 0, blocks_now = 0, it_end[2] = {0, 0};
-    int cur = 0;                    // status buffer of the chunk that is outstanding between driver passes
-    bool done = false;              // no more chunks are enqueued for this pipe (drained, evicted or parked)
-    bool any = false;               // a status has been read since the newest batch began
-    unsigned long long rays = 0;    // from the last status read: rays listed
-    unsigned long long old = 0;     // ... and paths of the OLDEST unresolved batch still in this pipe's pool
-    bool old_valid = false;         // ... counted by a launch that already knew which batch is the oldest
-    uint32_t old_from = 0;          // iterations >= old_from count survivors of the current oldest batch
-    bool dry[kWfRing] = {};         // a status of this pipe saw that batch's queue empty (its OWN snapshot: its
-                                    // survivor count only means something once no more such paths can start here)
-    uint32_t evict_next = 0;        // evict_mask for the first shade launch of the next chunk
+    uint32_t it = 0;                // the next iteration to enqueue (numbers are never reused: a run starts where the last one
+    uint32_t it_first = 0;          // ended, so a late status write of the last run cannot be taken for one of this run)
     uint32_t it_confirmed = 0;      // iterations < it_confirmed are known to have completed (a status of them was read)
+    uint32_t chunk = 2, tail_bound = 0, blocks_now = 0;
+    // Status records: iteration i's is written by the shade launch of iteration i + 1 into slot i % kStatusRing and
+    // is pending while it_confirmed <= i < it.
+    bool st_counted[kStatusRing] = {};      // that iteration's shade launch counted the alive paths per batch
+    bool done = false;              // flush: nothing more is enqueued for this pipe (drained or emptied by eviction)
+    bool any = false;               // a status has been read since the newest batch began
+    unsigned long long rays = 0;    // from the last status: rays listed by its last iteration
+    uint32_t bound = 0;             // ... and the most rays one shard listed
+    uint32_t alive[kWfRing] = {};   // per batch id, from this pipe's last status that counted: paths alive in its pool
+    bool alive_valid[kWfRing] = {};
+    bool dry[kWfRing] = {};         // a status of this pipe saw that batch's queue empty (its OWN view: its count of
+                                    // alive paths only bounds the future once no more such paths can start here)
+    uint32_t evict_next = 0;        // evict_mask for the next shade launch
 };
 
 // A batch of samples whose paths are (or may still be) in flight.
 struct WfBatch {
     uint32_t n = 0, last_sample = 0, id = 0;
-    uint32_t from_it[crt_ctx::kMaxPipes] = {};   // per pipe: statuses of iterations >= from_it know this batch's queue
+    uint32_t from_it[crt_ctx::kMaxPipes] = {};   // per pipe: chunks enqueued from this iteration on know the batch
+    bool evicting = false;          // its last paths are being moved to the side pools (or none are left)
+    uint32_t need_mask = 0;         // pipes whose next shade launch evicts ...
+    uint32_t launched_mask = 0;     // ... and those that have enqueued it (ev_evict[p][id] recorded)
 };
 
-// The pipeline's state between driver calls.  Up to kWfRing batches are in flight, each with its own work
-// queue, staging buffer and side pools (indexed by the batch id, which a path carries in its flags).  A batch
-// normally ENDS PARKED: crt_trace returns while its queue still holds a few iterations' worth of work and one
-// chunk of iterations is enqueued; the next call publishes its queue and dead slots re-arm from the oldest
-// non-empty queue on -- the pool never runs dry between calls, however small the calls are.  Once only a few
-// paths of the OLDEST batch are left, k_wf_shade moves them to the side pool, k_wf_finish runs them to their
-// end and the batch is resolved (batches resolve in order: the accumulator is summed in sample order) --
-// the path-length tail of a batch runs under the bulk of the next ones instead of on a nearly empty GPU.
-// wf_flush() does the same for whatever is left at crt_sync; every call that reads or changes state flushes.
 struct WfRun {
-    bool live = false;              // pipes are forked; every pipe has one outstanding chunk in status buffer [cur]
+    bool live = false;              // the pipes are forked and hold (or may hold) paths
     int K = 0;
-    uint32_t P = 0, Pp = 0, list_cap = 0, trace_blocks = 0;
+    uint32_t P = 0, Pp = 0, list_cap = 0, trace_blocks = 0, ring = 4;
     uint32_t seg_wps[kWfRing] = {};             // per batch id: work items per shard / in total
     unsigned long long seg_total[kWfRing] = {};
     WfPipe pipes[crt_ctx::kMaxPipes];
     std::vector<WfBatch> open;                  // unresolved batches, oldest first; back() = the newest
-    bool queue_left[kWfRing] = {};              // pipe 0's view: that batch's queue still holds work
-    bool work_left = false;                     // any of them
-    unsigned long long left_its = ~0ull;        // iterations until the newest batch's queue is dry (estimate)
-    uint32_t rate_it = 0;                       // pipe 0's iteration and the newest batch's work consumed at its last status
-    unsigned long long rate_consumed = 0;
+    bool queue_left[kWfRing] = {};              // that batch's queue still holds work (latest knowledge of any pipe)
+    unsigned long long consumed[kWfRing] = {};  // work items taken from it (latest knowledge)
+    unsigned long long consumed_total = 0;      // ... summed over all batches since the pool started
+    bool work_left = false;                     // any open batch's queue holds work
+    double per_it = 0.0;                        // work items one iteration of one pipe consumes while work is there (estimate)
+    unsigned long long rate_consumed = 0;       // sample point of that estimate
+    unsigned long long rate_its = 0;
     uint32_t listed_until[kWfRing][crt_ctx::kMaxPipes] = {};   // per id and pipe: launches of iterations < this may look at that queue
+    bool resolved_recorded[kWfRing] = {};       // ev_resolved[id] has been recorded since the pool started
+    bool all_evicting = false;                  // flush: everything alive was sent to the side pools
+    int poll_next = 0;                          // round robin over the pipes for blocking waits
 };
 
 struct WfConfig {
@@ -519,16 +566,18 @@ WfConfig wf_config(crt_ctx *c, uint32_t n)
     g.npix_padded = g.tiles_x * g.tiles_y * 64u;
     g.npix = (size_t)c->tw * c->th;
     g.work_total = (unsigned long long)n * g.npix_padded;
-    // pool: about 1/4 of the batch's paths in flight, between 1 M and 8 M slots (measured best on S2 with up to
-    // four batches in flight: whole frame and 1/2, 1/4, 1/8 shares, profiles/r01_steady_pool.log)
-    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 23, std::max<unsigned long long>(1u << 20, g.work_total / 4u));
-    // (an explicit pool may exceed one batch's work: several batches share it, but never more than the ring holds)
-    const unsigned long long most = c->wf_pool ? g.work_total * (unsigned long long)std::max(1, c->wf_ring - 1) : g.work_total;
+    // pool: between 1 M and 8 M slots, about a quarter of a LARGE batch's paths (measured best on S2 with several
+    // batches in flight: whole frame and 1/2, 1/4, 1/8 shares, profiles/r01_steady_pool.log); a stream of small
+    // batches shares the pool, so it is sized by the tile, not by one call's samples
+    const unsigned long long per_pixel = std::max<unsigned long long>(g.work_total / 4u, (unsigned long long)g.npix_padded * (unsigned long long)c->wf_pool_spp);
+    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 23, std::max<unsigned long long>(1u << 20, per_pixel));
+    // (a pool may exceed one batch's work: several batches share it, but never more than the ring holds)
+    const unsigned long long most = g.work_total * (unsigned long long)std::max(1u, std::min<uint32_t>(c->wf_ring, kWfRing) - 1u);
     if ((unsigned long long)P > most) P = (uint32_t)most;
     // Two (or more) half-pools on separate streams: one half's shade pass (an HBM stream) overlaps
-    // the other half's traversal (latency-bound), measured +8 % on S2.  Small jobs keep one pipe.
+    // the other half's traversal (latency-bound).  Small pools keep one pipe.
     int K = std::max(1, std::min(c->wf_pipes, (int)crt_ctx::kMaxPipes));
-    if (P < (1u << 18) || (c->wf_pool == 0 && g.work_total < 6000000ull)) K = 1;   // (1-2 spp of a 1080p frame: 7-10 % faster on one pipe)
+    if (P < (1u << 19)) K = 1;
     // slots per pipe: a whole number of shade blocks for every one of the 64 shards when possible
     // (measured: a 1/8 strip takes 13.0 ms with such a pool and 15.1 ms with one 0.4 % smaller)
     uint32_t Pp = P / (uint32_t)K;
@@ -548,23 +597,47 @@ int wf_resolve_batch(crt_ctx *c, const WfBatch &b)
     WfParams R = r.pipes[0].W;
     R.batch_id = b.id; R.n_samples = b.n;
     HIPCHK(c, wf_launch_resolve(R, b.last_sample, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_resolved[b.id], c->stream));    // the id's queue, staging buffer and side pools are free after this
+    r.resolved_recorded[b.id] = true;
     c->last_launches++;
     return CRT_OK;
 }
 
-// Iterations are enqueued in chunks; after each chunk the small control blocks are copied back
-// (asynchronously) so the host can tell how far the pool has drained.  One chunk is always
-// enqueued AHEAD of the status being waited for, so the GPU never idles on the host; the
-// price is at most one chunk of nearly empty iterations at the end.
-int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
+// Which queues the next launches re-arm from: the open batches whose queue still holds work, oldest first.
+void wf_set_queues(crt_ctx *c, WfPipe &pp)
 {
-    WfPipe &pp = c->run->pipes[p];
+    WfRun &r = *c->run;
+    uint32_t order[kWfRing], n = 0;
+    for (const WfBatch &b : r.open) if (r.queue_left[b.id] && n < kWfRing) order[n++] = b.id;
+    if (n == 0) order[n++] = r.open.empty() ? 0u : r.open.back().id;       // (all dry: any valid entry)
+    for (uint32_t k = 0; k < kWfRing; k++) pp.W.seg_order[k] = order[k < n ? k : n - 1];
+    pp.W.seg_n = n;
+}
+
+int wf_retire_front(crt_ctx *c);
+
+// Enqueue `iters` iterations of pipe p.  The shade launch of iteration i also writes iteration i - 1's status record.
+int wf_enqueue(crt_ctx *c, int p, uint32_t iters)
+{
+    WfRun &r = *c->run;
+    WfPipe &pp = r.pipes[p];
+    if (pp.it - pp.it_confirmed + iters >= (uint32_t)kStatusRing || iters == 0) return fail(c, CRT_EDEVICE, "wavefront driver: status ring overrun");
     pp.W.tail_bound = pp.tail_bound;
-    for (uint32_t k = 0; k < pp.chunk; k++, pp.it++) {
+    pp.W.count_alive = r.open.size() > 1 ? 1u : 0u;
+    wf_set_queues(c, pp);
+    const bool evicted = pp.evict_next != 0;
+    for (uint32_t k = 0; k < iters; k++, pp.it++) {
         pp.W.evict_mask = pp.evict_next;
+        pp.W.status_out = pp.it > pp.it_first ? c->d_status[p] + (pp.it - 1u) % kStatusRing : nullptr;
         HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
+        if (pp.it > pp.it_first) HIPCHK(c, hipEventRecord(c->ev_status[p][(pp.it - 1u) % kStatusRing], pp.stream));   // (blocking waits fall back on it)
+        pp.st_counted[pp.it % kStatusRing] = pp.W.count_alive != 0;
         if (pp.evict_next) {                                     // k_wf_finish may start once this launch is through
-            HIPCHK(c, hipEventRecord(c->ev_evict[p], pp.stream));
+            for (WfBatch &b : r.open)
+                if ((pp.evict_next >> b.id) & 1u) {
+                    HIPCHK(c, hipEventRecord(c->ev_evict[p][b.id], pp.stream));
+                    b.launched_mask |= 1u << p;
+                }
             pp.evict_next = 0; pp.W.evict_mask = 0;
         }
         if (c->time_kernels) {
@@ -584,246 +657,330 @@ int wf_enqueue_chunk(crt_ctx *c, int p, int buf)
         c->last_launches += 2;
         c->last_iterations++;
     }
-    pp.it_end[buf] = pp.it;
-    for (uint32_t k = 0; k < pp.W.seg_n; k++) c->run->listed_until[pp.W.seg_order[k]][p] = pp.it;
-    HIPCHK(c, hipMemcpyAsync(c->h_ctl[p][buf], pp.W.ctl, sizeof(WfCtl), hipMemcpyDeviceToHost, pp.stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_wq[p][buf], c->w_wq.p, kWfRing * sizeof(WfWorkQ), hipMemcpyDeviceToHost, pp.stream));
-    HIPCHK(c, hipEventRecord(c->ev_ctl[p][buf], pp.stream));
+    for (uint32_t k = 0; k < pp.W.seg_n; k++) r.listed_until[pp.W.seg_order[k]][p] = pp.it;
+    return evicted && !r.all_evicting ? wf_retire_front(c) : CRT_OK;   // a batch may have become ready for its finish pass
+}
+
+// k_wf_finish for the leading batches whose evicting launches are all enqueued, then their resolve passes -- on
+// the context's stream, which has nothing else to do while the pipes work.  One finish launch covers every pipe
+// of every such batch: its duration is that of the longest path in it (one lane per path, a bounce after the
+// other), so batches that are ready together cost one such tail, not one each.
+int wf_retire_front(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    size_t n = 0;
+    while (n < r.open.size() && r.open[n].evicting && (r.open[n].need_mask & ~r.open[n].launched_mask) == 0) n++;
+    if (n == 0) return CRT_OK;
+    WfFinishSegs G{};
+    auto launch = [&]() -> int {
+        if (G.n == 0) return CRT_OK;
+        WfParams F = r.pipes[0].W;
+        F.tail_bound = c->wf_side_ppw;
+        HIPCHK(c, wf_launch_finish(F, G, kWfSideCap, c->stream));
+        c->last_launches++;
+        G.n = 0;
+        return CRT_OK;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const WfBatch &b = r.open[i];
+        for (int p = 0; p < r.K; p++) {
+            if (!((b.need_mask >> p) & 1u)) continue;
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_evict[p][b.id], 0));
+            if (G.n == kWfFinishSegs) { int rc = launch(); if (rc) return rc; }
+            G.ctl[G.n] = r.pipes[p].W.ctl; G.base[G.n] = r.pipes[p].W.side_base[b.id]; G.batch[G.n] = b.id; G.n++;
+        }
+    }
+    { int rc = launch(); if (rc) return rc; }
+    for (size_t i = 0; i < n; i++) { int rc = wf_resolve_batch(c, r.open[i]); if (rc) return rc; }   // in order
+    r.open.erase(r.open.begin(), r.open.begin() + (long)n);
     return CRT_OK;
 }
 
-// After every pipe's evicting shade launch, run the evicted paths of batch `b` to their end and resolve the
-// batch -- on the context's stream, which has nothing else to do while the pipes work (a stream of its own
-// would be a fifth one, and streams beyond the hardware queues share one: a pipe queued behind a wait stalls).
-int wf_finish_side(crt_ctx *c, const WfBatch &b, uint32_t max_paths, uint32_t paths_per_wave)
+// Retirement decisions after a status: the oldest batches (never the newest -- flush does that one) whose queue is
+// dry for every pipe and of which few paths are left (alive slots only shrink once the queue is dry, so they still
+// fit when the launch runs) have them evicted by every pipe's next shade launch; none left: nothing to evict.
+int wf_retire(crt_ctx *c)
 {
     WfRun &r = *c->run;
-    for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_evict[p], 0));
-    for (int p = 0; p < r.K; p++) {
-        WfParams F = r.pipes[p].W;
-        F.batch_id = b.id;
-        F.tail_bound = paths_per_wave;
-        HIPCHK(c, wf_launch_finish(F, max_paths, c->stream));
-        c->last_launches++;
+    if (r.all_evicting) return CRT_OK;
+    const unsigned long long evict_at = std::min<unsigned long long>(c->wf_finish_at, kWfSideCap);
+    for (size_t i = 0; i + 1 < r.open.size(); i++) {
+        WfBatch &b = r.open[i];
+        if (b.evicting) continue;
+        bool ready = true;
+        unsigned long long tot = 0, mx = 0;
+        uint32_t mask = 0;
+        for (int p = 0; p < r.K; p++) {
+            const WfPipe &pp = r.pipes[p];
+            if (pp.done) continue;                               // (a drained pipe holds no path at all)
+            ready = ready && pp.alive_valid[b.id] && pp.dry[b.id];
+            tot += pp.alive[b.id]; mx = std::max<unsigned long long>(mx, pp.alive[b.id]);
+            if (pp.alive[b.id]) mask |= 1u << p;
+        }
+        if (!ready) break;                                       // in order
+        if (tot != 0 && !(mx <= kWfSideCap && tot <= evict_at * (unsigned)r.K)) break;
+        b.evicting = true; b.need_mask = mask; b.launched_mask = 0;
+        for (int p = 0; p < r.K; p++) if ((mask >> p) & 1u) r.pipes[p].evict_next |= 1u << b.id;
     }
-    return wf_resolve_batch(c, b);
+    return wf_retire_front(c);
 }
 
-// The oldest batch is resolved: the next one becomes the one whose survivors the shade launches count.
-void wf_pop_oldest(crt_ctx *c)
+// One status record of pipe p has arrived: fold it into the driver's view.
+int wf_process_status(crt_ctx *c, int p)
 {
     WfRun &r = *c->run;
-    r.open.erase(r.open.begin());
-    const uint32_t oldest = r.open.empty() ? 0u : r.open.front().id;
-    for (int p = 0; p < r.K; p++) {
+    WfPipe &pp = r.pipes[p];
+    const int slot = (int)(pp.it_confirmed % kStatusRing);
+    const WfStatus st = c->h_status[p][slot];                   // (the caller has seen it_end == it_confirmed + 1, with acquire)
+    const bool counted = pp.st_counted[slot];
+    if (st.it_end != pp.it_confirmed + 1u) return fail(c, CRT_EDEVICE, "wavefront driver: status record out of order (pipe %d: %u, expected %u)", p, st.it_end, pp.it_confirmed + 1u);
+    if (st.dropped) return fail(c, CRT_EDEVICE, "wavefront pipeline: a capacity guard dropped %u paths (pipe %d)", st.dropped, p);
+    pp.it_confirmed = st.it_end;
+    for (const WfBatch &b : r.open) {
+        if (st.it_end <= b.from_it[p]) continue;                 // from before that batch began: knows nothing about it
+        const uint32_t id = b.id;
+        if (!st.left[id]) { pp.dry[id] = true; r.queue_left[id] = false; }      // (monotone within a batch)
+        if (counted) { pp.alive[id] = st.alive[id]; pp.alive_valid[id] = true; }
+        if (st.consumed[id] > r.consumed[id]) { r.consumed_total += st.consumed[id] - r.consumed[id]; r.consumed[id] = st.consumed[id]; }
+    }
+    r.work_left = false;
+    for (const WfBatch &b : r.open) r.work_left = r.work_left || r.queue_left[b.id];
+    pp.rays = st.rays; pp.bound = st.bound;
+    if (!r.open.empty() && st.it_end > r.open.back().from_it[p]) pp.any = true;
+    // work one iteration of one pipe consumes: sampled over intervals at whose end work was still there
+    unsigned long long its = 0;
+    for (int q = 0; q < r.K; q++) its += r.pipes[q].it_confirmed;
+    if (its > r.rate_its) {
+        if (r.work_left && r.consumed_total > r.rate_consumed) {
+            const double sample = (double)(r.consumed_total - r.rate_consumed) / (double)(its - r.rate_its);
+            r.per_it = 0.5 * r.per_it + 0.5 * sample;
+        }
+        r.rate_its = its; r.rate_consumed = r.consumed_total;
+    }
+    if (getenv("CRT_DEBUG")) {
+        fprintf(stderr, "[crt] pipe %d it %u rays %llu open %zu work_left %d per_it %.0f alive", p, st.it_end, st.rays, r.open.size(), (int)r.work_left, r.per_it);
+        for (const WfBatch &b : r.open) fprintf(stderr, " %u:%u%s", b.id, pp.alive[b.id], b.evicting ? "e" : pp.dry[b.id] ? "d" : "");
+        fprintf(stderr, "\n");
+    }
+    return wf_retire(c);
+}
+
+// Look at pipe p's oldest pending status record; block = wait for it.  *got says whether one was processed.
+int wf_poll(crt_ctx *c, int p, bool block, bool *got)
+{
+    WfPipe &pp = c->run->pipes[p];
+    if (got) *got = false;
+    if (pp.it_confirmed >= pp.it) return CRT_OK;
+    const uint32_t want = pp.it_confirmed + 1u;
+    const int slot = (int)(pp.it_confirmed % kStatusRing);
+    const uint32_t *flag = &c->h_status[p][slot].it_end;
+    auto ready = [&]() { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == want; };
+    if (!ready()) {
+        if (!block) return CRT_OK;
+        // the record is written by the NEXT iteration's shade launch: make sure there is one
+        if (pp.it == want) { int rc = wf_enqueue(c, p, 1); if (rc) return rc; }
+        for (int spin = 0; spin < 2000 && !ready(); spin++) std::this_thread::yield();
+        if (!ready()) {
+            HIPCHK(c, hipEventSynchronize(c->ev_status[p][slot]));
+            if (!ready()) return fail(c, CRT_EDEVICE, "wavefront driver: status record of pipe %d iteration %u did not arrive", p, want - 1u);
+        }
+    }
+    if (got) *got = true;
+    return wf_process_status(c, p);
+}
+
+int wf_poll_all(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    for (int p = 0; p < r.K; p++)
+        for (;;) {
+            bool got = false;
+            int rc = wf_poll(c, p, false, &got);
+            if (rc) return rc;
+            if (!got) break;
+        }
+    return CRT_OK;
+}
+
+// Block until some status arrives (enqueueing iterations first where nothing is in flight).
+int wf_wait_progress(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    for (int p = 0; p < r.K; p++)
+        if (!r.pipes[p].done && r.pipes[p].it - r.pipes[p].it_confirmed < 2u) { int rc = wf_enqueue(c, p, r.pipes[p].chunk); if (rc) return rc; }
+    for (int k = 0; k < r.K; k++) {
+        const int p = (r.poll_next + k) % r.K;
+        if (r.pipes[p].it == r.pipes[p].it_confirmed) continue;
+        r.poll_next = (p + 1) % r.K;
+        return wf_poll(c, p, true, nullptr);
+    }
+    return CRT_OK;
+}
+
+// Is there room for another batch: a free batch id whose previous user's finish / resolve passes have COMPLETED (the
+// new batch's queue reset waits for them on the device; a reset that waits stalls every pipe behind it).
+bool wf_has_room(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    if (r.open.size() >= (size_t)r.ring) return false;
+    const uint32_t id = r.open.empty() ? 0u : (r.open.back().id + 1u) % r.ring;
+    if (!r.resolved_recorded[id]) return true;
+    return hipEventQuery(c->ev_resolved[id]) == hipSuccess;
+}
+
+// Feed the pool: enqueue the iterations the published work needs (see the head of this section).  for_room = false:
+// return once they are enqueued (the call does not wait for its work); for_room = true: keep feeding and reading
+// statuses until there is room for another batch (back-pressure of a caller that publishes faster than the pool works).
+int wf_pump(crt_ctx *c, bool for_room)
+{
+    WfRun &r = *c->run;
+    const uint32_t max_ahead = (uint32_t)std::max(c->wf_ahead, c->wf_chunk + 1);   // iterations in flight per pipe before the driver waits
+    for (int guard = 0; guard < 4000000; guard++) {
+        int rc = wf_poll_all(c);
+        if (rc) return rc;
+        if (for_room && wf_has_room(c)) return CRT_OK;
+        unsigned long long backlog = 0, inflight = 0;
+        for (const WfBatch &b : r.open)
+            if (r.queue_left[b.id] && r.seg_total[b.id] > r.consumed[b.id]) backlog += r.seg_total[b.id] - r.consumed[b.id];
+        for (int p = 0; p < r.K; p++) inflight += r.pipes[p].it - r.pipes[p].it_confirmed;
+        const double per_it = std::max(r.per_it, 1024.0);
+        const double need = (double)backlog - per_it * (double)inflight * c->wf_feed;
+        if (!(need > 0.0)) {
+            if (!for_room) return CRT_OK;
+            // nothing to feed, but the oldest batch has yet to retire: its last paths need iterations (or only its
+            // finish / resolve passes are still running on the device)
+            if (r.open.size() < (size_t)r.ring) {
+                const uint32_t id = (r.open.back().id + 1u) % r.ring;
+                HIPCHK(c, hipEventSynchronize(c->ev_resolved[id]));
+                continue;
+            }
+            rc = wf_wait_progress(c);
+            if (rc) return rc;
+            continue;
+        }
+        // the pipe with the fewest iterations in flight takes the next chunk
+        int p = 0;
+        for (int q = 1; q < r.K; q++)
+            if (r.pipes[q].it - r.pipes[q].it_confirmed < r.pipes[p].it - r.pipes[p].it_confirmed) p = q;
         WfPipe &pp = r.pipes[p];
-        pp.W.oldest_id = oldest;
-        pp.old_from = pp.it; pp.old_valid = false; pp.old = 0;
+        if (pp.it - pp.it_confirmed + (uint32_t)c->wf_chunk >= (uint32_t)kStatusRing - 1u || pp.it - pp.it_confirmed >= max_ahead) {
+            rc = wf_poll(c, p, true, nullptr);                  // back-pressure: wait for this pipe's oldest chunk
+            if (rc) return rc;
+            continue;
+        }
+        const double want = std::ceil(need / per_it / (double)r.K);
+        const uint32_t iters = (uint32_t)std::min<double>((double)c->wf_chunk, std::max(1.0, want));
+        rc = wf_enqueue(c, p, iters);
+        if (rc) return rc;
     }
+    return fail(c, CRT_EDEVICE, "wavefront driver: pump did not converge");
 }
 
-// Which queues the next chunks re-arm from: the open batches whose queue still holds work, oldest first.
-void wf_set_queues(crt_ctx *c)
-{
-    WfRun &r = *c->run;
-    uint32_t order[kWfRing], n = 0;
-    for (const WfBatch &b : r.open) if (r.queue_left[b.id] && n < kWfRing) order[n++] = b.id;
-    if (n == 0) order[n++] = r.open.empty() ? 0u : r.open.back().id;       // (all dry: any valid entry)
-    for (int p = 0; p < r.K; p++) {
-        for (uint32_t k = 0; k < kWfRing; k++) r.pipes[p].W.seg_order[k] = order[k < n ? k : n - 1];
-        r.pipes[p].W.seg_n = n;
-    }
-}
-
-// Enqueue iterations and read statuses until the newest batch is parked (to_end = false: its queue is nearly
-// empty and there is room for another batch) or everything is finished and resolved (to_end = true).
-int wf_drive(crt_ctx *c, bool to_end)
+// Run everything in the pool to its end and resolve every batch.
+int wf_finish_all(crt_ctx *c)
 {
     WfRun &r = *c->run;
     const int K = r.K;
-    const unsigned long long evict_at = std::min<unsigned long long>(c->wf_finish_at, kWfSideCap);
     const unsigned long long flush_at = std::min<unsigned long long>(c->wf_flush_at, kWfSideCap);
-    int active = 0;
-    for (int p = 0; p < K; p++) { r.pipes[p].done = false; active++; }
-    bool oldest_evicting = false, all_evicting = false;
-    while (active > 0) {
+    for (int p = 0; p < K; p++) { r.pipes[p].done = false; r.pipes[p].chunk = (uint32_t)c->wf_chunk; }
+    r.all_evicting = false;
+    int active = K;
+    for (unsigned long long guard = 0; active > 0; guard++) {
+        if (guard > 4000000ull) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+        // one chunk is always enqueued AHEAD of the status being waited for, so the GPU never idles on the host
+        // (iteration i's status record is written by the launch of iteration i + 1: three in flight = one ahead of the
+        // one whose record is being waited for)
         for (int p = 0; p < K; p++)
-            if (!r.pipes[p].done) { int rc = wf_enqueue_chunk(c, p, r.pipes[p].cur ^ 1); if (rc) return rc; }   // speculative
-        // the chunk just enqueued carried the eviction of the oldest batch's last paths: finish and resolve it
-        if (oldest_evicting) {
-            int rc = wf_finish_side(c, r.open.front(), kWfSideCap, c->wf_side_ppw);
-            if (rc) return rc;
-            wf_pop_oldest(c);
-            oldest_evicting = false;
+            while (!r.pipes[p].done && r.pipes[p].it - r.pipes[p].it_confirmed < 3u) { int rc = wf_enqueue(c, p, 1); if (rc) return rc; }
+        int p = -1;
+        for (int k = 0; k < K && p < 0; k++) {
+            const int q = (r.poll_next + k) % K;
+            if (!r.pipes[q].done && r.pipes[q].it > r.pipes[q].it_confirmed) p = q;
         }
-        for (int p = 0; p < K; p++) {
-            WfPipe &pp = r.pipes[p];
-            if (pp.done) continue;
-            HIPCHK(c, hipEventSynchronize(c->ev_ctl[p][pp.cur]));
-            const uint32_t it_seen = pp.it_end[pp.cur];          // the status covers iterations < it_seen
-            pp.it_confirmed = it_seen;
-            const WfBatch &newest = r.open.back();
-            if (it_seen <= newest.from_it[p]) { pp.cur ^= 1; continue; }          // from before the newest batch began
-            auto seg_left = [&](uint32_t id, unsigned long long &consumed) {
-                bool left = false;
-                consumed = 0;
-                for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-                    const unsigned long long lo = (unsigned long long)sidx * r.seg_wps[id];
-                    const unsigned long long size = lo < r.seg_total[id] ? std::min<unsigned long long>(r.seg_wps[id], r.seg_total[id] - lo) : 0;
-                    const unsigned long long cur = c->h_wq[p][pp.cur][id].work[sidx].cur;
-                    if (cur < size) left = true;
-                    consumed += std::min(cur, size);
-                }
-                return left;
-            };
-            unsigned long long newest_consumed = 0;
-            for (const WfBatch &b : r.open) {
-                unsigned long long cons = 0;
-                const bool left = seg_left(b.id, cons);
-                if (!left) pp.dry[b.id] = true;
-                if (&b == &newest) newest_consumed = cons;
-                if (p == 0) r.queue_left[b.id] = left;          // monotone within a batch: once false it stays false
-            }
-            if (p == 0) {
-                r.work_left = false;
-                for (const WfBatch &b : r.open) r.work_left = r.work_left || r.queue_left[b.id];
-                // How many iterations until the newest batch's queue is dry.  Chunks shrink as that comes close when
-                // no further batch can take over: what is enqueued ahead of the status that shows the queues empty
-                // runs on a nearly empty pool, and the host needs only ~20 us per launch to keep up.
-                const uint32_t its = it_seen - r.rate_it;
-                if (!r.queue_left[newest.id]) r.left_its = 0;
-                else if (its > 0 && newest_consumed > r.rate_consumed) {
-                    const unsigned long long per_it = (newest_consumed - r.rate_consumed) / its;
-                    r.left_its = (r.seg_total[newest.id] - newest_consumed) / std::max<unsigned long long>(per_it, 1);
-                }
-                if (to_end || r.open.size() >= (size_t)c->wf_ring) {
-                    const uint32_t chunk = r.left_its >= 6 ? (uint32_t)c->wf_chunk : 1u;
-                    for (int q = 0; q < K; q++) r.pipes[q].chunk = chunk;
-                }
-                r.rate_it = it_seen; r.rate_consumed = newest_consumed;
-                wf_set_queues(c);
-            }
-            const WfCtl *hc = c->h_ctl[p][pp.cur];
-            if (hc->dropped) return fail(c, CRT_EDEVICE, "wavefront pipeline: a capacity guard dropped %u paths (pipe %d)", hc->dropped, p);
-            unsigned long long rays = 0, old = 0;
-            uint32_t bound = 0;
-            for (uint32_t sidx = 0; sidx < kWfShards; sidx++) {
-                const WfShard &sh = hc->shard[(it_seen - 1) & 3u][sidx];
-                // per-shard bound for later iterations: slots never change shard and none are re-armed once the
-                // queues are empty, so no list of a shard can ever grow beyond the slots alive in it now
-                uint32_t alive_here = 0;
-                for (int k = 0; k < 4; k++) { rays += sh.n[k]; alive_here += sh.n[k]; }
-                bound = std::max(bound, alive_here);
-                old += sh.old;
-            }
-            pp.rays = rays; pp.any = true;
-            if (it_seen > pp.old_from) { pp.old = old; pp.old_valid = true; }
-            if (getenv("CRT_DEBUG")) fprintf(stderr, "[crt] pipe %d it %u rays %llu old %llu open %zu work_left %d bound %u\n", p, it_seen, rays, old, r.open.size(), (int)r.work_left, bound);
-            // pipe 0's view of the queues can lag the others by a chunk; a pipe with no rays while work
-            // may be left simply keeps going (its dead slots re-arm as soon as they see work)
-            if (!r.work_left && rays == 0) { pp.done = true; pp.old = 0; pp.old_valid = true; pp.cur ^= 1; active--; continue; }   // every alive slot lists a ray
-            if (!to_end) {
-                // Park: the newest batch's queue is nearly dry -- NEARLY, so that the next call can publish its
-                // queue while this one still holds work and the chunk already enqueued ahead keeps the GPU busy --
-                // and the ring has room for another batch.
-                if (r.open.size() < (size_t)c->wf_ring && r.left_its < (unsigned long long)c->wf_park_its) { pp.done = true; pp.cur ^= 1; active--; continue; }
-            } else if (!r.work_left && !all_evicting) {
-                if (rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull) && c->wf_tail_walk) {
-                    // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
-                    // the ray lists instead of the whole pool and the grids shrink.
-                    pp.tail_bound = std::max<uint32_t>(64u, (bound + 63u) & ~63u);
-                    pp.blocks_now = (uint32_t)std::min<unsigned long long>(r.trace_blocks, std::max<unsigned long long>(64, rays / 32u + 64u));
-                }
-            }
-            if (pp.it - newest.from_it[p] > 100000u) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
-            pp.cur ^= 1;
+        if (p < 0) break;
+        r.poll_next = (p + 1) % K;
+        int rc = wf_poll(c, p, true, nullptr);
+        if (rc) return rc;
+        WfPipe &pp = r.pipes[p];
+        // chunks shrink as the queues run dry: what is enqueued ahead of the status that shows them empty runs on a
+        // nearly empty pool, and the host needs only ~20 us per launch to keep up
+        if (!r.work_left) pp.chunk = 1;
+        // every alive slot lists a ray: no rays and no work means this pipe is drained (another pipe's view of the
+        // queues can lag; a pipe with no rays while work may be left simply keeps going)
+        if (!r.work_left && pp.any && pp.rays == 0) { pp.done = true; active--; continue; }
+        if (!r.work_left && pp.any && c->wf_tail_walk && pp.rays < std::min<unsigned long long>((unsigned long long)r.Pp / 4u, 65536ull)) {
+            // The tail: no path can start any more, so ray counts only shrink from here.  Shade walks
+            // the ray lists instead of the whole pool and the grids shrink.  Per-shard bound for later iterations:
+            // slots never change shard and none are re-armed once the queues are empty, so no list of a shard can
+            // ever grow beyond the slots alive in it now.
+            pp.tail_bound = std::max<uint32_t>(64u, (pp.bound + 63u) & ~63u);
+            pp.blocks_now = (uint32_t)std::min<unsigned long long>(r.trace_blocks, std::max<unsigned long long>(64, pp.rays / 32u + 64u));
         }
-        // The oldest batch (when it is not the newest): its queue is dry for every pipe and few of its paths are
-        // left (alive slots only shrink, so they still fit when the launch runs) -- the next shade launch of every
-        // pipe moves them to the side pool; or none are left at all -- it is resolved right away.
-        if (r.open.size() > 1 && !oldest_evicting && !all_evicting && active > 0) {
-            const WfBatch &ob = r.open.front();
+        // once few paths are left altogether, everything alive goes to the side pools and the pool is done
+        if (!r.work_left && flush_at > 0) {
             bool ready = true;
-            unsigned long long old = 0, old_max = 0;
-            for (int p = 0; p < K; p++) {
-                const WfPipe &pp = r.pipes[p];
-                if (pp.done) continue;                           // (a drained pipe holds no path at all)
-                ready = ready && pp.old_valid && pp.dry[ob.id];
-                old += pp.old; old_max = std::max(old_max, pp.old);
-            }
-            if (ready && old == 0) { int rc = wf_resolve_batch(c, ob); if (rc) return rc; wf_pop_oldest(c); }
-            else if (ready && old_max <= kWfSideCap && old <= evict_at * (unsigned)K) {
-                for (int p = 0; p < K; p++) if (!r.pipes[p].done) r.pipes[p].evict_next = 1u << ob.id;
-                oldest_evicting = true;
-            }
-        }
-        // to_end: once few paths are left altogether, everything alive goes to the side pools and the pool is done
-        if (to_end && !r.work_left && !all_evicting && !oldest_evicting && active > 0 && flush_at > 0) {
-            bool ready = true;
-            for (int p = 0; p < K; p++) {
-                if (r.pipes[p].done) continue;
-                ready = ready && r.pipes[p].any && r.pipes[p].rays <= flush_at;
+            for (int q = 0; q < K; q++) {
+                if (r.pipes[q].done) continue;
+                ready = ready && r.pipes[q].any && r.pipes[q].rays <= flush_at;
             }
             if (ready) {
                 uint32_t mask = 0;
                 for (const WfBatch &b : r.open) mask |= 1u << b.id;
-                for (int p = 0; p < K; p++) {
-                    WfPipe &pp = r.pipes[p];
-                    if (pp.done) continue;
-                    pp.evict_next = mask;
-                    const uint32_t chunk = pp.chunk;
-                    pp.chunk = 1;                                // one more iteration: its shade launch empties the pool
-                    int rc = wf_enqueue_chunk(c, p, pp.cur ^ 1);
-                    pp.chunk = chunk;
+                for (int q = 0; q < K; q++) {
+                    WfPipe &pq = r.pipes[q];
+                    if (pq.done) continue;
+                    pq.evict_next = mask;
+                    rc = wf_enqueue(c, q, 1);                     // one more iteration: its shade launch empties the pool
                     if (rc) return rc;
-                    pp.done = true; pp.rays = 0; pp.cur ^= 1;
+                    pq.done = true; pq.rays = 0;
                 }
                 active = 0;
-                all_evicting = true;
+                r.all_evicting = true;
             }
         }
     }
-    bool empty = !r.work_left;
-    for (int p = 0; p < K; p++) empty = empty && r.pipes[p].rays == 0;
-    if (to_end || empty) {
-        if (!all_evicting) {
-            // everything enqueued for the pipes comes before the resolve passes on the context's stream
-            for (int p = 0; p < K; p++) {
-                HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
-            }
-        }
-        while (!r.open.empty()) {                                // in order: the accumulator is summed in sample order
-            // (when everything was evicted nothing else is running: few paths per wave end sooner)
-            int rc = all_evicting ? wf_finish_side(c, r.open.front(), (uint32_t)flush_at, c->wf_flush_ppw) : wf_resolve_batch(c, r.open.front());
-            if (rc) return rc;
-            wf_pop_oldest(c);
-        }
-        if (c->counting) {
-            // fold the pipes' counters into the context's
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            unsigned long long tot[CRT_NCOUNTERS];
-            HIPCHK(c, hipMemcpy(tot, c->d_counters.p, sizeof tot, hipMemcpyDeviceToHost));
-            for (int p = 0; p < K; p++) {
-                HIPCHK(c, hipMemcpy(c->h_ctl[p][0], c->w_ctl[p].p, sizeof(WfCtl), hipMemcpyDeviceToHost));
-                for (int k = 0; k < CRT_NCOUNTERS; k++) tot[k] += c->h_ctl[p][0]->counters[k];
-                for (int k = 0; k < 8; k++) c->probes[k] += c->h_ctl[p][0]->counters[8 + k];
-                HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
-            }
-            HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
-        }
+    // everything enqueued for the pipes comes before the finish / resolve passes on the context's stream
+    for (int p = 0; p < K; p++) {
+        HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
     }
-    if (to_end || empty) {
-        // (checked by wf_check_dropped after the caller's stream synchronisation)
-        for (int p = 0; p < K; p++)
-            HIPCHK(c, hipMemcpyAsync(&c->h_dropped[p], &c->w_ctl[p].p->dropped, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        // the pool is empty; the next batch sets the pipes up afresh (after everything enqueued here)
+    while (!r.open.empty()) {                                    // in order: the accumulator is summed in sample order
+        const WfBatch &b = r.open.front();
+        if (r.all_evicting || b.evicting) {
+            // (nothing else is running: few paths per wave end sooner)
+            WfFinishSegs G{};
+            for (int p = 0; p < K; p++) { G.ctl[G.n] = r.pipes[p].W.ctl; G.base[G.n] = r.pipes[p].W.side_base[b.id]; G.batch[G.n] = b.id; G.n++; }
+            WfParams F = r.pipes[0].W;
+            F.tail_bound = c->wf_flush_ppw;
+            // (a batch whose eviction began before the final one may hold up to a side pool's worth)
+            HIPCHK(c, wf_launch_finish(F, G, b.evicting ? kWfSideCap : (uint32_t)std::max<unsigned long long>(flush_at, 1), c->stream));
+            c->last_launches++;
+        }
+        int rc = wf_resolve_batch(c, b);
+        if (rc) return rc;
+        r.open.erase(r.open.begin());
+    }
+    // (the status records still pending describe an empty pool; the capacity guards are checked below)
+    for (int p = 0; p < K; p++) r.pipes[p].it_confirmed = r.pipes[p].it;
+    if (c->counting) {
+        // fold the pipes' counters into the context's
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        unsigned long long tot[CRT_NCOUNTERS];
+        HIPCHK(c, hipMemcpy(tot, c->d_counters.p, sizeof tot, hipMemcpyDeviceToHost));
+        unsigned long long pc[CRT_NCOUNTERS_DEV];
         for (int p = 0; p < K; p++) {
-            HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+            HIPCHK(c, hipMemcpy(pc, &c->w_ctl[p].p->counters[0], sizeof pc, hipMemcpyDeviceToHost));
+            for (int k = 0; k < CRT_NCOUNTERS; k++) tot[k] += pc[k];
+            for (int k = 0; k < 8; k++) c->probes[k] += pc[8 + k];
+            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
         }
-        r.live = false;
+        HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
     }
+    // (checked by wf_check_dropped after the caller's stream synchronisation: k_wf_finish's guard)
+    for (int p = 0; p < K; p++)
+        HIPCHK(c, hipMemcpyAsync(&c->h_dropped[p], &c->w_ctl[p].p->dropped, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    // the pool is empty; the next batch sets the pipes up afresh
+    r.live = false;
     return CRT_OK;
 }
 
@@ -840,36 +997,51 @@ int wf_check_dropped(crt_ctx *c)
     return CRT_OK;
 }
 
-// Finish whatever the pipeline still holds (no-op when nothing is parked).
+// Finish whatever the pipeline still holds (no-op when nothing is in flight).
 int wf_flush(crt_ctx *c)
 {
     if (!c->run || !c->run->live) return CRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = wf_drive(c, true);
-    if (rc == CRT_OK && c->last_timed) HIPCHK(c, hipEventRecord(c->ev1, c->stream));   // crt_last_trace_ms covers the stragglers too
+    int rc = wf_finish_all(c);
+    if (rc != CRT_OK) {
+        // a failed drive leaves the pool in an unknown state: drain the streams and start afresh next time
+        for (int p = 0; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
+        (void)hipStreamSynchronize(c->stream);
+        c->run->live = false;
+        c->run->open.clear();
+        return rc;
+    }
+    if (c->last_timed) HIPCHK(c, hipEventRecord(c->ev1, c->stream));   // crt_last_trace_ms covers the stragglers too
     return rc;
 }
 
-// One batch of n samples through the wavefront pipeline (asynchronous except for the small
-// control-block readbacks that tell how far the pool has drained).
+// One batch of n samples through the wavefront pipeline.
 int wf_trace_batch(crt_ctx *c, uint32_t n)
 {
     if (!c->run) c->run = new WfRun();
     WfRun &r = *c->run;
     const WfConfig g = wf_config(c, n);
     if (g.npix == 0 || n == 0) { int rc = wf_flush(c); c->sample += n; return rc; }
-    // counting folds counters on the host after every batch; otherwise batches end parked
+    // counting folds counters on the host after every batch; otherwise batches are pipelined across calls
     const bool defer = c->wf_defer && !c->counting;
     const size_t staging_elems = (size_t)n * g.npix;
     const uint32_t side_slots = kWfRing * (uint32_t)crt_ctx::kMaxPipes * kWfSideCap;   // side pools first, then the pool
-    if (r.live && (g.K != r.K || g.Pp != r.Pp || c->w_staging[0].n < staging_elems || r.open.size() >= (size_t)c->wf_ring)) {
+    // A live pool is kept as it is unless this batch wants one more than twice as large or small (e.g. 64-spp calls
+    // after 1-spp calls), or the staging buffers are too small.
+    if (r.live && ((unsigned long long)g.P > 2ull * r.P || 2ull * g.P < (unsigned long long)r.P || c->w_staging[0].n < staging_elems)) {
         int rc = wf_flush(c);
         if (rc) return rc;
     }
-    int rc = wf_ensure(c, (size_t)g.P + side_slots, staging_elems, g.list_per_pipe * (size_t)g.K);
+    const uint32_t pool_slots = r.live ? r.P : g.P;
+    const size_t list_elems = r.live ? (size_t)8 * r.list_cap * kWfShards * (size_t)r.K : g.list_per_pipe * (size_t)g.K;
+    if (!r.live) {
+        // batches in flight at most: the staging buffers (one per batch id) stay within ~32 GB
+        uint32_t ring = std::max(2u, std::min<uint32_t>(c->wf_ring, kWfRing));
+        while (ring > 4u && (double)ring * (double)staging_elems * 16.0 > 32.0e9) ring--;
+        r.ring = ring;
+    }
+    int rc = wf_ensure(c, (size_t)pool_slots + side_slots, staging_elems, list_elems, r.ring);
     if (rc) return rc;
-    r.rate_consumed = 0;
-    r.left_its = ~0ull;
     if (!r.live) {
         r.K = g.K; r.P = g.P; r.Pp = g.Pp; r.list_cap = g.list_cap;
         r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
@@ -877,12 +1049,19 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         WfBatch nb;
         nb.n = n; nb.last_sample = c->sample + n; nb.id = 0;
         r.open.push_back(nb);
-        r.rate_it = 0;
         r.seg_total[0] = g.work_total; r.seg_wps[0] = g.work_per_shard;
-        for (uint32_t b = 0; b < kWfRing; b++) { r.queue_left[b] = false; for (int p = 0; p < crt_ctx::kMaxPipes; p++) r.listed_until[b][p] = 0; }
+        for (uint32_t b = 0; b < kWfRing; b++) {
+            r.queue_left[b] = false; r.consumed[b] = 0; r.resolved_recorded[b] = false;
+            for (int p = 0; p < crt_ctx::kMaxPipes; p++) r.listed_until[b][p] = 0;
+        }
         r.queue_left[0] = r.work_left = true;
+        r.consumed_total = 0; r.rate_consumed = 0; r.rate_its = 0;
+        r.per_it = (double)g.Pp;                                 // an empty pool takes a slot's worth per slot
+        r.all_evicting = false; r.poll_next = 0;
         for (int p = 0; p < r.K; p++) {
+            const uint32_t it0 = r.pipes[p].it + 2u * (uint32_t)kStatusRing;
             r.pipes[p] = WfPipe();
+            r.pipes[p].it = r.pipes[p].it_first = r.pipes[p].it_confirmed = it0;
             r.pipes[p].chunk = (uint32_t)c->wf_chunk;
             WfParams &W = r.pipes[p].W;
             W.sc = c->sc;
@@ -893,12 +1072,12 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
                 for (int k = 0; k < 4; k++)
                     W.list[b][k] = c->w_list_ext.p + g.list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * g.list_cap * kWfShards;
             for (uint32_t b = 0; b < kWfRing; b++) {
-                W.staging[b] = c->w_staging[b].p;
+                W.staging[b] = c->w_staging[b < r.ring ? b : 0].p;
                 W.side_base[b] = (b * (uint32_t)crt_ctx::kMaxPipes + (uint32_t)p) * kWfSideCap;
                 W.seg[b] = WfSeg{0, 64, 0};
                 W.seg_order[b] = 0;
             }
-            W.batch_id = 0; W.oldest_id = 0; W.keep_pool = 0; W.evict_mask = 0;
+            W.batch_id = 0; W.count_alive = 0; W.keep_pool = 0; W.evict_mask = 0; W.status_out = nullptr;
             W.ctl = c->w_ctl[p].p; W.wq = c->w_wq.p;
             W.slot_base = side_slots + g.Pp * (uint32_t)p; W.reset_wq = (p == 0) ? 1u : 0u;
             W.P = g.Pp; W.x0 = c->x0; W.y0 = c->y0; W.tw = c->tw; W.th = c->th;
@@ -926,8 +1105,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             r.pipes[p].stream = c->pipe_stream[p];
             r.pipes[p].blocks_now = r.trace_blocks;
         }
-        // The context's stream is the control stream: it resets the work queue and forks the pipes (and,
-        // later, finishes stragglers and resolves).  The pipes run on their own streams.
+        // The context's stream sets the pool up and forks the pipes (and, later, finishes stragglers and
+        // resolves).  The pipes run on their own streams.
         HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
         HIPCHK(c, wf_launch_tea(r.pipes[0].W, c->w_tea.p, c->stream));          // per-pixel RNG seed words of this tile
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -935,17 +1114,19 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
             if (p > 0) HIPCHK(c, wf_launch_init(r.pipes[p].W, r.pipes[p].stream));
         }
-        // the first chunk of every pipe (from here on one chunk per pipe is always outstanding)
-        for (int p = 0; p < r.K; p++) { rc = wf_enqueue_chunk(c, p, 0); if (rc) return rc; }
         r.live = true;
     } else {
-        // The parked batches keep their slots, queues and staging buffers; this batch takes the next id and its
+        // room in the ring first (back-pressure: the oldest batch has to retire; the pool is fed meanwhile)
+        rc = wf_pump(c, true);
+        if (rc) return rc;
+        // The batches in flight keep their slots, queues and staging buffers; this one takes the next id and its
         // work flows into the slots that are free once the older queues are dry.
         WfBatch nb;
-        nb.n = n; nb.last_sample = c->sample + n; nb.id = (r.open.back().id + 1u) % kWfRing;
+        nb.n = n; nb.last_sample = c->sample + n; nb.id = (r.open.back().id + 1u) % r.ring;
         const uint32_t id = nb.id;
         r.seg_total[id] = g.work_total; r.seg_wps[id] = g.work_per_shard;
         r.queue_left[id] = r.work_left = true;
+        r.consumed[id] = 0;
         for (int p = 0; p < r.K; p++) {
             WfPipe &pp = r.pipes[p];
             nb.from_it[p] = pp.it;
@@ -953,30 +1134,34 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             pp.W.n_samples = n;
             pp.W.batch_id = id; pp.W.keep_pool = 1;
             pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
-            pp.any = false; pp.evict_next = 0; pp.chunk = (uint32_t)c->wf_chunk;
-            pp.dry[id] = false;
-            // (while it was the only batch, the oldest was also the newest and nothing was counted: the survivor
-            // counts of the oldest batch start with the launches enqueued from here on)
-            if (r.open.size() == 1) { pp.old_from = pp.it; pp.old_valid = false; pp.old = 0; }
+            pp.any = false; pp.chunk = (uint32_t)c->wf_chunk; pp.done = false;
+            pp.dry[id] = false; pp.alive_valid[id] = false; pp.alive[id] = 0;
         }
-        r.open.push_back(nb);
-        r.rate_it = r.pipes[0].it;
-        wf_set_queues(c);
-        // This batch's queue and side counters are reset on the control stream.  The batch that used the id
-        // before is resolved; a launch still in flight may have that queue in its list, though (enqueued while
-        // it held work), and would take the NEW work with the OLD batch's parameters: the reset waits for such
-        // a pipe's outstanding chunk.  Otherwise the pipes only wait for the reset, not for each other.
+        // This batch's queue and side counters are reset on a stream of their own, which waits only for what it must:
+        // a launch still in flight that has the id's OLD queue in its list (enqueued while that held work; it would
+        // take the new work with the old batch's parameters), and the finish / resolve passes of the batch that
+        // used the id before (they read its side pools and staging buffer).  The pipes wait for the reset, not for
+        // each other, and not for the straggler kernels on the context's stream.
         for (int p = 0; p < r.K; p++)
             if (r.listed_until[id][p] > r.pipes[p].it_confirmed) {
-                HIPCHK(c, hipEventRecord(c->ev_join[p], r.pipes[p].stream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[p], 0));
+                HIPCHK(c, hipEventRecord(c->ev_pub_join[p], r.pipes[p].stream));
+                HIPCHK(c, hipStreamWaitEvent(c->pub_stream, c->ev_pub_join[p], 0));
             }
-        for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->stream));   // (one block each)
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        if (r.resolved_recorded[id]) HIPCHK(c, hipStreamWaitEvent(c->pub_stream, c->ev_resolved[id], 0));
+        for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->pub_stream));   // (one block each)
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->pub_stream));
         for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
+        r.open.push_back(nb);
     }
     c->sample += n;
-    return wf_drive(c, !defer);
+    rc = wf_pump(c, false);
+    if (rc == CRT_OK && !defer) rc = wf_flush(c);
+    if (rc != CRT_OK && r.live) {
+        for (int p = 0; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
+        (void)hipStreamSynchronize(c->stream);
+        r.live = false; r.open.clear();
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1029,18 +1214,18 @@ void crt_destroy(crt_ctx *c)
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
     c->w_vis.release(); c->w_list_ext.release(); c->w_tea.release(); c->w_wq.release();
+    if (c->pub_stream) (void)hipStreamSynchronize(c->pub_stream);
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
         c->w_ctl[p].release();
-        for (int b = 0; b < 2; b++) {
-            if (c->h_ctl[p][b]) (void)hipHostFree(c->h_ctl[p][b]);
-            if (c->ev_ctl[p][b]) (void)hipEventDestroy(c->ev_ctl[p][b]);
-        }
+        if (c->h_status[p]) (void)hipHostFree(c->h_status[p]);
+        for (int k = 0; k < crt_ctx::kStatusSlots; k++) if (c->ev_status[p][k]) (void)hipEventDestroy(c->ev_status[p][k]);
         if (c->pipe_stream[p]) (void)hipStreamDestroy(c->pipe_stream[p]);
         if (c->ev_join[p]) (void)hipEventDestroy(c->ev_join[p]);
-        if (c->ev_evict[p]) (void)hipEventDestroy(c->ev_evict[p]);
+        if (c->ev_pub_join[p]) (void)hipEventDestroy(c->ev_pub_join[p]);
+        for (uint32_t b = 0; b < kWfRing; b++) if (c->ev_evict[p][b]) (void)hipEventDestroy(c->ev_evict[p][b]);
     }
-    for (int p = 0; p < crt_ctx::kMaxPipes; p++)
-        for (int b = 0; b < 2; b++) if (c->h_wq[p][b]) (void)hipHostFree(c->h_wq[p][b]);
+    for (uint32_t b = 0; b < kWfRing; b++) if (c->ev_resolved[b]) (void)hipEventDestroy(c->ev_resolved[b]);
+    if (c->pub_stream) (void)hipStreamDestroy(c->pub_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->h_dropped) (void)hipHostFree(c->h_dropped);
 
@@ -1098,6 +1283,9 @@ int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const voi
     S.nlight = (uint32_t)nlight;
     S.inv_nlight = 1.0f / (float)S.nlight;                       // :372-373
     S.hit_pad = scene_hit_pad(c->prims, c->camera);
+    S.nf_last[0] = S.nf_last[1] = kNoHit;
+    for (size_t i = c->prims.size(); i-- > 0 && S.nf_last[1] == kNoHit;)
+        if (c->prims[i].category != 2u) (S.nf_last[0] == kNoHit ? S.nf_last[0] : S.nf_last[1]) = (uint32_t)i;
     camera_frame(c->camera, S.cam);
 
     HIPCHK(c, c->d_spectra.alloc(nspectra * kNLambda));
@@ -1430,9 +1618,11 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_flush_at")) { c->wf_flush_at = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
     if (!std::strcmp(name, "wf_side_ppw")) { c->wf_side_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_flush_ppw")) { c->wf_flush_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
-    if (!std::strcmp(name, "wf_ring")) { c->wf_ring = (int)std::min<int64_t>(kWfRing, std::max<int64_t>(2, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_ring")) { c->wf_ring = (int)std::min<int64_t>((int64_t)kWfRing, std::max<int64_t>(2, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_chunk")) { c->wf_chunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, value)); return CRT_OK; }
-    if (!std::strcmp(name, "wf_park_its")) { c->wf_park_its = (int)std::max<int64_t>(0, value); return CRT_OK; }
+    if (!std::strcmp(name, "wf_ahead")) { c->wf_ahead = (int)std::min<int64_t>(32, std::max<int64_t>(2, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_pool_spp")) { c->wf_pool_spp = (int)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_feed_pct")) { c->wf_feed = (double)std::min<int64_t>(400, std::max<int64_t>(10, value)) / 100.0; return CRT_OK; }
     if (!std::strcmp(name, "wf_tail_walk")) { c->wf_tail_walk = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }

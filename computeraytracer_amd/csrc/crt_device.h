@@ -46,6 +46,8 @@ struct DevScene {
     uint32_t nspectra;
     uint32_t nlight;
     float hit_pad;
+    uint32_t nf_last[2];   // array positions of the last and the second-to-last patch / sphere (kNoHit: none): what the
+                           // reference's loop returns for a ray with a NaN in its direction (crt_wavefront.hip, NEE)
     float inv_nlight;      // 1.0f / f32(nlight)
     uint32_t W, H;         // full image
     float qbase[3], qscale[3];  // plane = qbase + q * qscale (quantised nodes)
@@ -81,8 +83,8 @@ constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8
 // ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
 constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;
 constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
-constexpr uint32_t kWfBatchShift = 5;                           // 2 bits: which of the (up to kWfRing) batches in flight the path belongs to
-constexpr uint32_t kWfRing = 4;                                 // batch ids cycle 0..kWfRing-1: queues, staging buffers, side pools are indexed by id
+constexpr uint32_t kWfBatchShift = 25;                          // 5 bits: which of the (up to kWfRing) batches in flight the path belongs to
+constexpr uint32_t kWfRing = 32;                                // batch ids cycle 0..ring-1 (ring <= kWfRing): queues, staging buffers, side pools are indexed by id
 // Stragglers: once only a few paths of a batch are left (its queue is long empty, the pool is busy with the
 // next batch), k_wf_shade moves them out of the pool into a small side pool, where k_wf_finish runs them to
 // their end on another stream.  Side-pool slots precede the pool in the same arrays:
@@ -95,8 +97,9 @@ constexpr uint32_t kWfSideCap = 65536;
 // the ray lists; traversal waves and re-arming waves pick a non-empty shard with one
 // wave-wide load + ballot.
 constexpr uint32_t kWfShards = 64;
-// rays listed by shade per class / fetch cursor of trace / slots still alive for the OLDEST unresolved batch
-struct WfShard { uint32_t n[4], cur, old, pad[26]; };
+// rays listed by shade per class / fetch cursor of trace / slots still alive after the shade launch, per batch id
+struct WfShard { uint32_t n[4], cur, pad0[27], alive[kWfRing]; };
+static_assert(sizeof(WfShard) == 256, "two lines per shard: the list counters and cursor, the per-batch counts");
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
@@ -111,13 +114,39 @@ struct WfCtl {                       // device control block, one per context
 // still holds a few iterations' worth, so the pool never runs dry between batches.
 struct WfWorkQ {
     WfWork work[kWfShards];
-    uint32_t work_done, pad_[31];    // set once every work shard is exhausted (saves the scans)
+    uint32_t work_done;              // set once every work shard is exhausted (saves the scans)
+    uint32_t work_per_shard;         // the queue's extent (k_wf_init copies WfSeg here for write_status)
+    unsigned long long work_total;
+    uint32_t pad_[28];
 };
+static_assert(sizeof(WfWorkQ) == (kWfShards + 1) * 128, "whole lines");
 // One batch's share of the parameters (indexed by batch id like the queues and the staging buffers).
 struct WfSeg {
     unsigned long long work_total;   // n_samples * npix_padded
     uint32_t work_per_shard;         // work items per shard (multiple of 64)
     uint32_t first_sample;
+};
+
+// What the host needs to know about an iteration, reduced on the device (write_status in crt_wavefront.hip) into one
+// small record in pinned host memory.
+struct WfStatus {
+    uint32_t it_end;                       // the status describes the state after iterations < it_end of this pipe
+    uint32_t dropped;                      // WfCtl::dropped
+    uint32_t bound;                        // largest number of rays one shard listed in the last iteration
+    uint32_t pad_;
+    unsigned long long rays;               // rays listed in the last iteration (= alive slots once the queues are dry)
+    unsigned long long consumed[kWfRing];  // work items taken from that batch's queue so far (all pipes)
+    uint32_t left[kWfRing];                // 1: that batch's queue still holds work
+    uint32_t alive[kWfRing];               // paths of that batch alive in THIS pipe's pool after its last shade launch
+};
+
+// k_wf_finish runs the side-pool paths of several (batch, pipe) pairs in one launch: segment s = blocks
+// [s * blocks_per_seg, (s + 1) * blocks_per_seg), paths side_base .. + min(side_count, kWfSideCap) of that pipe's control block.
+constexpr uint32_t kWfFinishSegs = 32;
+struct WfFinishSegs {
+    struct WfCtl *ctl[kWfFinishSegs];
+    uint32_t base[kWfFinishSegs], batch[kWfFinishSegs];
+    uint32_t n, blocks_per_seg;
 };
 
 struct WfParams {
@@ -129,7 +158,8 @@ struct WfParams {
     uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
     float4 *staging[kWfRing];        // finished samples, per batch id (several batches can be in flight)
     uint32_t batch_id;           // id of the newest batch (k_wf_init: the batch being set up; k_wf_resolve / k_wf_finish: the batch to resolve / finish)
-    uint32_t oldest_id;              // id of the oldest unresolved batch: k_wf_shade counts its surviving paths
+    WfStatus *status_out;            // k_wf_shade: where its first wave writes the PREVIOUS iteration's status record (pinned host memory), or null
+    uint32_t count_alive;            // k_wf_shade: count the alive paths per batch id (WfShard::alive) -- needed once more than one batch is in flight
     uint32_t keep_pool;              // k_wf_init: leave the slots and list counters alone (paths of the batches before live on)
     uint32_t side_base[kWfRing];     // first side-pool slot of this pipe, per batch id
     uint32_t evict_mask;             // k_wf_shade: bit b = move the alive paths of batch id b to the side pool first

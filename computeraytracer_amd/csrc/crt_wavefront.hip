@@ -115,7 +115,7 @@ __device__ __forceinline__ f4 nee_term(const DevScene &S, uint32_t l_slot, f3 po
     return (le * weight_l) / pdf_l;
 }
 
-struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary, old; };
+struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary; uint32_t batch; };
 struct ShadeCnt { uint32_t rays = 0, bounces = 0, shadow = 0, hits = 0, paths = 0, prims = 0, walk = 0; };
 
 // One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
@@ -235,18 +235,18 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                         const float cos_theta = max_(0.0f, dot(nrm, ldir));
                         if (!sh_finite) {
                             // A non-finite shadow ray (the light sample coincides with the hit point, or a light record
-                            // with non-finite coordinates): the reference's loop decides in its own order -- a NaN passes
-                            // every reject-form test (:546,:557,:566,:605,:609), so the last patch / sphere that is not
-                            // excluded is "the closest hit" -- and the NEE term (NaN then) is added right here when that
-                            // is the light (:700, :393-400); the single-kernel form takes the same route.
-                            const float2 rr = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, pos.x, pos.y, pos.z,
-                                                                ldir.x, ldir.y, ldir.z, b_index);
-                            const uint32_t w_slot = f_bits(rr.y);
+                            // with non-finite coordinates): normalize() has put a NaN into its direction, and under the
+                            // reference's reject-form tests (:546,:557,:566,:605,:609) a NaN passes every test of every
+                            // patch and sphere (never this project's triangles), so "the closest hit" of shadow_intersect
+                            // is simply the LAST patch / sphere of the array that is not excluded -- the loop's result in
+                            // closed form (S.nf_last, found at upload).  If that is the light (:700) the NEE term is added:
+                            // le = spec * max(0, NaN) = 0 and pdf_l = NaN make it NaN in every wavelength (:393-400).
+                            const uint32_t w = S.nf_last[0] != b_index ? S.nf_last[0] : S.nf_last[1];
                             if (COUNT) cn.prims += S.nprim;
-                            if (w_slot != kNoHit && f_bits(S.prim[3 * (size_t)w_slot + 1].w) == include) {
+                            if (w != kNoHit && w == include) {
                                 if (COUNT) cn.hits++;
-                                const f4 nee = nee_term(S, w_slot, pos, ldir, rr.x, cos_theta, f_bits(L0.w), wl);
-                                R.radiance = R.radiance + (brdf * nee) * R.beta;
+                                const float qn = bits_f(0x7FC00000u);
+                                R.radiance = R.radiance + f4{qn, qn, qn, qn};
                             }
                         } else if (l_slot != kNoHit && cos_theta > 0.0f) {
                             if (COUNT) cn.hits++;
@@ -442,8 +442,55 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
         P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
     }
-    const bool old = alive && ((R.flags >> kWfBatchShift) & (kWfRing - 1u)) == P.oldest_id && P.oldest_id != P.batch_id;
-    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, old};
+    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, (R.flags >> kWfBatchShift) & (kWfRing - 1u)};
+}
+
+// What the host's driver needs to know about iteration it_end - 1 of this pipe (lane i looks at shard i of
+// everything), written by the first wave of the NEXT shade launch straight into a pinned host record: it_end goes last,
+// behind a system-scope fence, and the host polls for it -- no kernel, copy or event on the pipe's critical path.
+__device__ __noinline__ void write_status(const WfCtl *ctl, const WfWorkQ *wq, uint32_t it_end, WfStatus *out)
+{
+    // (out of line and in groups of eight batch ids: inlined and fully unrolled it would cost every wave of the shade
+    // kernel a third of its occupancy in registers)
+    const uint32_t lane = lane_id();
+    const WfShard &sh = ctl->shard[(it_end - 1u) & 3u][lane];
+    const uint32_t mine = sh.n[0] + sh.n[1] + sh.n[2] + sh.n[3];
+    unsigned long long rays = mine;
+    uint32_t bound = mine;
+    for (int off = 32; off > 0; off >>= 1) {
+        rays += __shfl_xor(rays, off, 64);
+        bound = max(bound, (uint32_t)__shfl_xor((int)bound, off, 64));
+    }
+    if (lane == 0) { out->dropped = ctl->dropped; out->bound = bound; out->pad_ = 0; out->rays = rays; }
+#pragma unroll 1
+    for (uint32_t g = 0; g < kWfRing; g += 8u) {
+        unsigned long long cur[8];
+        uint32_t alive[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {                      // the group's loads first: one round trip, not eight
+            cur[k] = __hip_atomic_load(&wq[g + k].work[lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive[k] = sh.alive[g + k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t b = g + k;
+            const uint32_t wps = wq[b].work_per_shard;
+            const unsigned long long wtot = wq[b].work_total, lo = (unsigned long long)lane * wps;
+            const unsigned long long size = lo < wtot ? min((unsigned long long)wps, wtot - lo) : 0ull;
+            unsigned long long cons = min(cur[k], size);
+            const unsigned long long left = __ballot(cur[k] < size);
+            uint32_t al = alive[k];
+            for (int off = 32; off > 0; off >>= 1) {
+                al += (uint32_t)__shfl_xor((int)al, off, 64);
+                cons += __shfl_xor(cons, off, 64);
+            }
+            if (lane == 0) { out->alive[b] = al; out->consumed[b] = cons; out->left[b] = left ? 1u : 0u; }
+        }
+    }
+    if (lane == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&out->it_end, it_end, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <bool COUNT>
@@ -452,9 +499,12 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     const DevScene &S = P.sc;
     const uint32_t ring = it & 3u, lbuf = it & 1u;
     WfCtl *ctl = P.ctl;
+    static_assert(kWfShards == 64, "one lane per shard");
+    if (blockIdx.x == 0 && threadIdx.x < 64u && P.status_out != nullptr) write_status(P.ctl, P.wq, it, P.status_out);   // of the previous iteration
     if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
         WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
-        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0; nx.old = 0;
+        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
+        for (uint32_t b = 0; b < kWfRing; b++) nx.alive[b] = 0;
     }
     uint32_t slot, my_shard;
     bool in_pool;
@@ -519,11 +569,20 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         const bool cl0 = emit_ext && ext_primary, cl1 = emit_ext && !ext_primary;
         const bool cl2 = emit_sh && sh_primary, cl3 = emit_sh && !sh_primary;
         const unsigned long long m0 = __ballot(cl0), m1 = __ballot(cl1), m2 = __ballot(cl2), m3 = __ballot(cl3);
-        const unsigned long long mo = __ballot(so.old);          // paths of the oldest unresolved batch still in the pool
         WfShard &sh = ctl->shard[ring][my_shard];
+        if (P.count_alive) {
+            // paths still in the pool, per batch id: the host retires a batch (eviction of its last paths, resolve)
+            // by these counts.  A wave holds paths of one to three batches as a rule: one ballot + atomic for each.
+            unsigned long long am = __ballot(so.alive);
+            while (am) {
+                const uint32_t b = (uint32_t)__shfl((int)so.batch, __ffsll((long long)am) - 1, 64);
+                const unsigned long long m = __ballot(so.alive && so.batch == b);
+                if (lane == 0) atomicAdd(&sh.alive[b], (uint32_t)__popcll(m));
+                am &= ~m;
+            }
+        }
         uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
         if (lane == 0) {
-            if (mo) atomicAdd(&sh.old, (uint32_t)__popcll(mo));
             if (m0) b0 = atomicAdd(&sh.n[0], (uint32_t)__popcll(m0));
             if (m1) b1 = atomicAdd(&sh.n[1], (uint32_t)__popcll(m1));
             if (m2) b2 = atomicAdd(&sh.n[2], (uint32_t)__popcll(m2));
@@ -954,19 +1013,20 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
 // k_wf_finish: one lane per side-pool path, run to the path's end (shade step, then trace what it emits,
 // ...) with the single-ray BVH2 walk.  Runs on its own stream while the pool works on the next batch.
 template <bool COUNT>
-__global__ __launch_bounds__(64) void k_wf_finish(const WfParams P)
+__global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFinishSegs G)
 {
     __shared__ int lds_stack[kStackDepth * 64];
     const DevScene &S = P.sc;
-    WfCtl *ctl = P.ctl;
+    const uint32_t seg = blockIdx.x / G.blocks_per_seg, blk = blockIdx.x % G.blocks_per_seg;
+    WfCtl *ctl = G.ctl[seg];
     int *stk = lds_stack + lane_id();
     const uint32_t my_shard = 0;
     // P.tail_bound = paths per wave: a wave runs until its longest path ends and every bounce costs the
     // slowest lane's walk, so when the GPU has nothing else to do few paths per wave finish sooner
-    const uint32_t j = blockIdx.x * P.tail_bound + threadIdx.x;
-    const uint32_t count = min(ctl->side_count[P.batch_id], kWfSideCap);
+    const uint32_t j = blk * P.tail_bound + threadIdx.x;
+    const uint32_t count = min(ctl->side_count[G.batch[seg]], kWfSideCap);
     const bool mine = threadIdx.x < P.tail_bound && j < count;
-    const uint32_t slot = P.side_base[P.batch_id] + (mine ? j : 0u);
+    const uint32_t slot = G.base[seg] + (mine ? j : 0u);
     uint32_t flags = 0;
     if (mine) flags = P.misc[slot].y;
     bool alive = mine && (flags & kWfAlive);
@@ -1054,11 +1114,19 @@ __global__ void k_wf_init(const WfParams P)
     if (i < kWfShards) {
         WfCtl *c = P.ctl;
         if (!P.keep_pool)
-            for (int r = 0; r < 4; r++) { for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0; c->shard[r][i].cur = 0; c->shard[r][i].old = 0; }
+            for (int r = 0; r < 4; r++) {
+                for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0;
+                c->shard[r][i].cur = 0;
+                for (uint32_t b = 0; b < kWfRing; b++) c->shard[r][i].alive[b] = 0;
+            }
         if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else { for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; c->dropped = 0; } }
         if (P.reset_wq) {
             P.wq[P.batch_id].work[i].cur = 0;
-            if (i == 0) P.wq[P.batch_id].work_done = 0;
+            if (i == 0) {
+                P.wq[P.batch_id].work_done = 0;
+                P.wq[P.batch_id].work_per_shard = P.seg[P.batch_id].work_per_shard;
+                P.wq[P.batch_id].work_total = P.seg[P.batch_id].work_total;
+            }
         }
     }
 }
@@ -1103,15 +1171,17 @@ hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks
     return hipGetLastError();
 }
 
-hipError_t wf_launch_finish(const WfParams &P, uint32_t max_paths, hipStream_t s)
+hipError_t wf_launch_finish(const WfParams &P, WfFinishSegs G, uint32_t max_paths, hipStream_t s)
 {
-    if (P.tail_bound == 0u || P.tail_bound > 64u) return hipErrorInvalidValue;     // paths per wave
-    const uint32_t blocks = (std::min(max_paths, kWfSideCap) + P.tail_bound - 1u) / P.tail_bound;
-    if (blocks == 0) return hipSuccess;
-    if (P.count) hipLaunchKernelGGL((k_wf_finish<true>), dim3(blocks), dim3(64), 0, s, P);
-    else hipLaunchKernelGGL((k_wf_finish<false>), dim3(blocks), dim3(64), 0, s, P);
+    if (P.tail_bound == 0u || P.tail_bound > 64u || G.n > kWfFinishSegs) return hipErrorInvalidValue;     // paths per wave
+    G.blocks_per_seg = (std::min(max_paths, kWfSideCap) + P.tail_bound - 1u) / P.tail_bound;
+    if (G.blocks_per_seg == 0 || G.n == 0) return hipSuccess;
+    if (P.count) hipLaunchKernelGGL((k_wf_finish<true>), dim3(G.n * G.blocks_per_seg), dim3(64), 0, s, P, G);
+    else hipLaunchKernelGGL((k_wf_finish<false>), dim3(G.n * G.blocks_per_seg), dim3(64), 0, s, P, G);
     return hipGetLastError();
 }
+
+
 
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s)
 {

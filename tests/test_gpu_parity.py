@@ -356,7 +356,7 @@ def test_batches_pipelined_across_calls(renderer, orc):
             assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *frames[8])
             renderer.frame(1).sync()            # a different batch size continues correctly
             assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *frames[9])
-        # stream-ordered view of a bound output between calls: a complete frame, at most wf_ring - 1 calls old
+        # stream-ordered view of a bound output between calls: a complete frame, at most wf_ring calls old
         renderer.set_option("wf_defer", 1)
         dev = torch.device("cuda", 0)
         acc_t = torch.zeros((640, 640, 4), dtype=torch.float32, device=dev)
@@ -377,13 +377,13 @@ def test_batches_pipelined_across_calls(renderer, orc):
             torch.cuda.synchronize()
             for k, snap in seen:
                 snap = snap.cpu().numpy()
-                ok = [j for j in range(max(1, k - ring + 1), k + 1) if np.array_equal(snap, frames[2 * j][1])]
-                assert ok or (k < ring and not snap.any()), f"ring {ring}: after call {k} the bound framebuffer is no complete frame of the last {ring} calls"
+                ok = [j for j in range(max(1, k - ring), k + 1) if np.array_equal(snap, frames[2 * j][1])]
+                assert ok or (k <= ring and not snap.any()), f"ring {ring}: after call {k} the bound framebuffer is no complete frame of the last {ring} calls"
         assert np.array_equal(rgba_t.cpu().numpy(), frames[8][1])
         assert np.array_equal(bits(acc_t.cpu().numpy())[..., :3], bits(frames[8][0])[..., :3])
     finally:
         renderer.set_stream(None)
-        renderer.set_option("wf_defer", 1).set_option("wf_ring", 4)
+        renderer.set_option("wf_defer", 1).set_option("wf_ring", 32)
 
 
 def test_pipelined_calls_at_full_scale(renderer):
@@ -423,10 +423,10 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
     try:
         for epoch in range(int(os.environ.get("CRT_TEST_EPOCHS", "8"))):
             opts = {"wf_pool": int(rng.choice([0, 1 << 18, 1 << 19])), "wf_pipes": int(rng.choice([1, 2])),
-                    "wf_chunk": int(rng.choice([1, 2, 4])), "wf_park_its": int(rng.choice([0, 4, 1000])),
+                    "wf_chunk": int(rng.choice([1, 2, 4])), "wf_feed_pct": int(rng.choice([50, 100, 200])),
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
                     "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0])),
-                    "wf_ring": int(rng.choice([2, 3, 4]))}
+                    "wf_ring": int(rng.choice([2, 3, 4, 32])), "wf_pool_spp": int(rng.choice([1, 2, 4])), "wf_ahead": int(rng.choice([2, 3, 6]))}
             for k, v in opts.items():
                 renderer.set_option(k, v)
             rect = None
@@ -453,8 +453,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *full[total], rect=rect)
             assert renderer.sample == total
     finally:
-        for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 2, "wf_park_its": 4, "wf_finish_at": 32768,
-                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 4}.items():
+        for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 1, "wf_feed_pct": 100, "wf_finish_at": 32768, "wf_ahead": 3,
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 2}.items():
             renderer.set_option(k, v)
 
 

@@ -21,14 +21,13 @@ def t(spp, calls=80, n=2):
     return best * 1e3 / calls, host * 1e3 / calls
 
 
-for spp in (1, 2, 4):
+for spp in (1, 4):
     out = []
-    for opts in ({}, {'wf_pool': 1 << 22, 'wf_pipes': 2}, {'wf_pool': 1 << 23, 'wf_pipes': 2}, {'wf_chunk': 1}, {'wf_chunk': 1, 'wf_pool': 1 << 22, 'wf_pipes': 2},
-                 {'wf_finish_at': 65536}, {'wf_park_its': 1}):
+    for opts in ({}, {'wf_pool_spp': 4}, {'wf_pool_spp': 3}, {'wf_pool_spp': 4, 'wf_ahead': 2}, {'wf_pool_spp': 4, 'wf_ahead': 4}, {'wf_pool_spp': 4, 'wf_side_ppw': 16}, {'wf_pool_spp': 4, 'wf_finish_at': 65536}, {'wf_pool_spp': 4, 'wf_finish_at': 8192}, {'wf_ring': 16}, {'wf_chunk': 2}):
         for k, v in opts.items(): r.set_option(k, v)
         a, h = t(spp)
         out.append('%s: %.2f (host %.2f)' % (','.join('%s=%d' % kv for kv in opts.items()) or 'default', a, h))
-        for k, v in {'wf_pool': 0, 'wf_pipes': 2, 'wf_chunk': 2, 'wf_finish_at': 32768, 'wf_park_its': 4}.items(): r.set_option(k, v)
+        for k, v in {'wf_pool': 0, 'wf_pipes': 2, 'wf_chunk': 1, 'wf_finish_at': 32768, 'wf_feed_pct': 100, 'wf_pool_spp': 2, 'wf_ring': 32, 'wf_ahead': 3, 'wf_side_ppw': 64}.items(): r.set_option(k, v)
     print(name, spp, 'spp |', ' | '.join(out), flush=True)
 
 r.reset()

@@ -17,7 +17,7 @@ def t(calls=24, n=2):
 for name, bands in (('frame', None), ('1/2 bands', (8, 2, 1)), ('1/4 bands', (8, 4, 1)), ('1/8 bands', (8, 8, 3))):
     if bands: r.set_row_bands(*bands)
     out = []
-    for chunk, park, ppw in ((2, 4, 64), (4, 8, 64), (2, 8, 64), (2, 4, 16), (1, 4, 16)):
-        r.set_option('wf_chunk', chunk).set_option('wf_park_its', park).set_option('wf_side_ppw', ppw)
-        out.append('c%d p%d w%d: %.2f' % (chunk, park, ppw, t()))
+    for chunk, feed, ppw in ((2, 100, 64), (4, 100, 64), (2, 80, 64), (2, 125, 64), (1, 100, 16)):
+        r.set_option('wf_chunk', chunk).set_option('wf_feed_pct', feed).set_option('wf_side_ppw', ppw)
+        out.append('c%d f%d w%d: %.2f' % (chunk, feed, ppw, t()))
     print(name, ' | '.join(out), flush=True)
