@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -151,7 +152,7 @@ struct crt_ctx {
     int wf_chunk = 1;               // iterations per status record at most
     int wf_ahead = 3;               // iterations in flight per pipe before the pump waits for a status
     int wf_ring = 32;               // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
-    int wf_pool_spp = 2;            // automatic pool size: at least this many path slots per tile pixel (within 1 M .. 8 M)
+    int wf_pool_spp = 4;            // automatic pool size: at least this many path slots per tile pixel (within 1 M .. 8 M)
     double wf_feed = 1.0;           // pump: weight of the work the iterations in flight are expected to consume
     WfRun *run = nullptr;           // pipeline state between calls
     uint32_t wf_finish_at = 32768;  // paths of the oldest batch left (per pipe) at which they move to the side pool; 0 = never
@@ -163,13 +164,19 @@ struct crt_ctx {
     WfStatus *h_status[kMaxPipes] = {};                    // pinned host records, written by k_wf_status ...
     WfStatus *d_status[kMaxPipes] = {};                    // ... through these device pointers
     hipEvent_t ev_status[kMaxPipes][kStatusSlots] = {};
+    hipEvent_t ev_done[kMaxPipes][kStatusSlots] = {};      // after the traversal launch of that iteration
     uint32_t *h_dropped = nullptr;                         // pinned [kMaxPipes]: WfCtl::dropped after the last flush
     bool wf_host_ready = false;                            // the streams / events / pinned buffers below exist
     hipStream_t pipe_stream[kMaxPipes] = {};               // the pipes' own streams (the context's stream sets up, finishes stragglers and resolves)
     hipStream_t pub_stream = nullptr;                      // publishes a new batch's queue (waits only for what it must)
+    static constexpr int kFinishStreams = 3;
+    hipStream_t fin_stream[kFinishStreams] = {};           // k_wf_finish launches (lowest priority; each lasts as long as its longest path,
+    hipEvent_t ev_fin[kFinishStreams] = {};                //  so consecutive ones overlap); the resolve passes wait for these events
+    int fin_next = 0;
     hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {}, ev_pub_join[kMaxPipes] = {};
     hipEvent_t ev_evict[kMaxPipes][kWfRing] = {};          // after the shade launch of that pipe that evicts that batch id
     hipEvent_t ev_resolved[kWfRing] = {};                  // after the resolve pass of the batch that used the id last
+    hipEvent_t ev_pub[kWfRing] = {};                       // after the queue reset of the batch that uses the id now
     bool time_kernels = false;
     std::vector<hipEvent_t> kev;    // event pairs around k_wf_trace launches
     float last_trace_kernel_ms = 0.0f;
@@ -182,7 +189,7 @@ namespace {
 
 int fail(crt_ctx *c, int code, const char *fmt, ...)
 {
-    char buf[512];
+    char buf[2048];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -462,12 +469,22 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uin
         }
         if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         if (!c->pub_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->pub_stream, hipStreamNonBlocking));
+        for (int f = 0; f < crt_ctx::kFinishStreams; f++) {
+            if (!c->fin_stream[f]) {
+                int least = 0, greatest = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->fin_stream[f], hipStreamNonBlocking, least));
+            }
+            if (!c->ev_fin[f]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fin[f], hipEventDisableTiming));
+        }
         if (!c->h_dropped) {
             HIPCHK(c, hipHostMalloc((void **)&c->h_dropped, crt_ctx::kMaxPipes * sizeof(uint32_t), hipHostMallocDefault));
             std::memset(c->h_dropped, 0, crt_ctx::kMaxPipes * sizeof(uint32_t));
         }
-        for (uint32_t b = 0; b < kWfRing; b++)
+        for (uint32_t b = 0; b < kWfRing; b++) {
             if (!c->ev_resolved[b]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_resolved[b], hipEventDisableTiming));
+            if (!c->ev_pub[b]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pub[b], hipEventDisableTiming));
+        }
         for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
             if (!c->w_ctl[p].p) {
                 HIPCHK(c, c->w_ctl[p].alloc(1));
@@ -479,8 +496,10 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uin
                 std::memset(c->h_status[p], 0, kStatusRing * sizeof(WfStatus));
                 HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_status[p], c->h_status[p], 0));
             }
-            for (int k = 0; k < kStatusRing; k++)
+            for (int k = 0; k < kStatusRing; k++) {
                 if (!c->ev_status[p][k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_status[p][k], hipEventDisableTiming));
+                if (!c->ev_done[p][k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done[p][k], hipEventDisableTiming));
+            }
             if (!c->ev_join[p]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[p], hipEventDisableTiming));
             if (!c->ev_pub_join[p]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pub_join[p], hipEventDisableTiming));
             for (uint32_t b = 0; b < kWfRing; b++)
@@ -507,6 +526,7 @@ struct WfPipe {
     uint32_t it = 0;                // the next iteration to enqueue (numbers are never reused: a run starts where the last one
     uint32_t it_first = 0;          // ended, so a late status write of the last run cannot be taken for one of this run)
     uint32_t it_confirmed = 0;      // iterations < it_confirmed are known to have completed (a status of them was read)
+    uint32_t it_done = 0;           // iterations < it_done are known to have completed (their traversal launch's event has)
     uint32_t chunk = 2, tail_bound = 0, blocks_now = 0;
     // Status records: iteration i's is written by the shade launch of iteration i + 1 into slot i % kStatusRing and
     // is pending while it_confirmed <= i < it.
@@ -526,6 +546,8 @@ struct WfPipe {
 struct WfBatch {
     uint32_t n = 0, last_sample = 0, id = 0;
     uint32_t from_it[crt_ctx::kMaxPipes] = {};   // per pipe: chunks enqueued from this iteration on know the batch
+    bool ready = true;              // its queue has been reset on the device (ev_pub[id] seen complete): launches may list it
+    uint32_t evict_bound = 0;       // the most paths one pipe held when the eviction was decided (sizes the finish launch)
     bool evicting = false;          // its last paths are being moved to the side pools (or none are left)
     uint32_t need_mask = 0;         // pipes whose next shade launch evicts ...
     uint32_t launched_mask = 0;     // ... and those that have enqueued it (ev_evict[p][id] recorded)
@@ -603,18 +625,42 @@ int wf_resolve_batch(crt_ctx *c, const WfBatch &b)
     return CRT_OK;
 }
 
+// The host has seen the batch's queue reset complete: from here on launches may list the queue, and the status
+// records of the iterations enqueued from here on describe THIS batch's queue (earlier ones may have looked at the
+// cursors of the id's previous user).
+bool wf_check_ready(crt_ctx *c, WfBatch &b, bool wait)
+{
+    if (b.ready) return true;
+    if (wait) { if (hipEventSynchronize(c->ev_pub[b.id]) != hipSuccess) return false; }
+    else if (hipEventQuery(c->ev_pub[b.id]) != hipSuccess) return false;
+    b.ready = true;
+    for (int p = 0; p < c->run->K; p++) b.from_it[p] = c->run->pipes[p].it;
+    return true;
+}
+
 // Which queues the next launches re-arm from: the open batches whose queue still holds work, oldest first.
 void wf_set_queues(crt_ctx *c, WfPipe &pp)
 {
     WfRun &r = *c->run;
     uint32_t order[kWfRing], n = 0;
-    for (const WfBatch &b : r.open) if (r.queue_left[b.id] && n < kWfRing) order[n++] = b.id;
+    for (WfBatch &b : r.open)
+        if (wf_check_ready(c, b, false) && r.queue_left[b.id] && n < kWfRing) order[n++] = b.id;
     if (n == 0) order[n++] = r.open.empty() ? 0u : r.open.back().id;       // (all dry: any valid entry)
     for (uint32_t k = 0; k < kWfRing; k++) pp.W.seg_order[k] = order[k < n ? k : n - 1];
     pp.W.seg_n = n;
 }
 
 int wf_retire_front(crt_ctx *c);
+std::string wf_state(crt_ctx *c);
+constexpr double kWfStallMs = 30000.0;     // a driver loop that makes no progress for this long gives up with CRT_EDEVICE
+
+bool wf_debug() { static const bool on = getenv("CRT_DEBUG") != nullptr; return on; }
+double wf_now_ms()
+{
+    static const auto t_ref = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ref).count();
+}
+
 
 // Enqueue `iters` iterations of pipe p.  The shade launch of iteration i also writes iteration i - 1's status record.
 int wf_enqueue(crt_ctx *c, int p, uint32_t iters)
@@ -654,6 +700,7 @@ int wf_enqueue(crt_ctx *c, int p, uint32_t iters)
             HIPCHK(c, hipEventRecord(c->kev[2 * (size_t)c->last_trace_kernel_launches + 1], pp.stream));
             c->last_trace_kernel_launches++;
         }
+        HIPCHK(c, hipEventRecord(c->ev_done[p][pp.it % kStatusRing], pp.stream));
         c->last_launches += 2;
         c->last_iterations++;
     }
@@ -671,26 +718,40 @@ int wf_retire_front(crt_ctx *c)
     size_t n = 0;
     while (n < r.open.size() && r.open[n].evicting && (r.open[n].need_mask & ~r.open[n].launched_mask) == 0) n++;
     if (n == 0) return CRT_OK;
+    // The finish launch goes to one of a few low-priority streams in turn (a launch lasts as long as its longest path,
+    // a few milliseconds on S2 whatever the number of paths, so consecutive launches must overlap or the retirement
+    // of small batches is bound by that latency); the resolve passes wait for it on the context's stream.
+    const int f = c->fin_next;
+    c->fin_next = (c->fin_next + 1) % crt_ctx::kFinishStreams;
+    hipStream_t fs = c->fin_stream[f];
     WfFinishSegs G{};
+    bool any = false;
+    uint32_t bound = 1;                                         // paths per (batch, pipe) at most: alive slots only shrink once a queue is dry
+    for (size_t i = 0; i < n; i++) bound = std::max(bound, r.open[i].evict_bound);
     auto launch = [&]() -> int {
         if (G.n == 0) return CRT_OK;
         WfParams F = r.pipes[0].W;
         F.tail_bound = c->wf_side_ppw;
-        HIPCHK(c, wf_launch_finish(F, G, kWfSideCap, c->stream));
+        HIPCHK(c, wf_launch_finish(F, G, bound, fs));
         c->last_launches++;
         G.n = 0;
+        any = true;
         return CRT_OK;
     };
     for (size_t i = 0; i < n; i++) {
         const WfBatch &b = r.open[i];
         for (int p = 0; p < r.K; p++) {
             if (!((b.need_mask >> p) & 1u)) continue;
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_evict[p][b.id], 0));
+            HIPCHK(c, hipStreamWaitEvent(fs, c->ev_evict[p][b.id], 0));
             if (G.n == kWfFinishSegs) { int rc = launch(); if (rc) return rc; }
             G.ctl[G.n] = r.pipes[p].W.ctl; G.base[G.n] = r.pipes[p].W.side_base[b.id]; G.batch[G.n] = b.id; G.n++;
         }
     }
     { int rc = launch(); if (rc) return rc; }
+    if (any) {
+        HIPCHK(c, hipEventRecord(c->ev_fin[f], fs));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fin[f], 0));
+    }
     for (size_t i = 0; i < n; i++) { int rc = wf_resolve_batch(c, r.open[i]); if (rc) return rc; }   // in order
     r.open.erase(r.open.begin(), r.open.begin() + (long)n);
     return CRT_OK;
@@ -719,7 +780,7 @@ int wf_retire(crt_ctx *c)
         }
         if (!ready) break;                                       // in order
         if (tot != 0 && !(mx <= kWfSideCap && tot <= evict_at * (unsigned)r.K)) break;
-        b.evicting = true; b.need_mask = mask; b.launched_mask = 0;
+        b.evicting = true; b.need_mask = mask; b.launched_mask = 0; b.evict_bound = (uint32_t)mx;
         for (int p = 0; p < r.K; p++) if ((mask >> p) & 1u) r.pipes[p].evict_next |= 1u << b.id;
     }
     return wf_retire_front(c);
@@ -758,7 +819,7 @@ int wf_process_status(crt_ctx *c, int p)
         r.rate_its = its; r.rate_consumed = r.consumed_total;
     }
     if (getenv("CRT_DEBUG")) {
-        fprintf(stderr, "[crt] pipe %d it %u rays %llu open %zu work_left %d per_it %.0f alive", p, st.it_end, st.rays, r.open.size(), (int)r.work_left, r.per_it);
+        fprintf(stderr, "[crt  %8.2f] pipe %d it %u rays %llu open %zu work_left %d per_it %.0f alive", wf_now_ms(), p, st.it_end, st.rays, r.open.size(), (int)r.work_left, r.per_it);
         for (const WfBatch &b : r.open) fprintf(stderr, " %u:%u%s", b.id, pp.alive[b.id], b.evicting ? "e" : pp.dry[b.id] ? "d" : "");
         fprintf(stderr, "\n");
     }
@@ -817,6 +878,43 @@ int wf_wait_progress(crt_ctx *c)
     return CRT_OK;
 }
 
+// Iterations of pipe p that are enqueued and have not completed.  (An iteration's status record only arrives with the
+// NEXT iteration's shade launch, so a pipe that has run out of launches would look busy for ever by the records alone.)
+uint32_t wf_in_flight(crt_ctx *c, int p)
+{
+    WfPipe &pp = c->run->pipes[p];
+    if (pp.it_done < pp.it_confirmed) pp.it_done = pp.it_confirmed;
+    while (pp.it_done < pp.it && hipEventQuery(c->ev_done[p][pp.it_done % kStatusRing]) == hipSuccess) pp.it_done++;
+    return pp.it - pp.it_done;
+}
+
+// The driver's state in a line (for the error message of a loop that does not make progress).
+std::string wf_state(crt_ctx *c)
+{
+    WfRun &r = *c->run;
+    char buf[256];
+    std::string out;
+    snprintf(buf, sizeof buf, "K %d ring %u open %zu work_left %d per_it %.0f all_evicting %d |", r.K, r.ring, r.open.size(), (int)r.work_left, r.per_it, (int)r.all_evicting);
+    out += buf;
+    for (int p = 0; p < r.K; p++) {
+        const WfPipe &pp = r.pipes[p];
+        snprintf(buf, sizeof buf, " pipe %d: it %u done %u confirmed %u rays %llu any %d finished %d evict %x |", p, pp.it, pp.it_done, pp.it_confirmed, pp.rays, (int)pp.any, (int)pp.done, pp.evict_next);
+        out += buf;
+    }
+    size_t shown = 0;
+    for (const WfBatch &b : r.open) {
+        if (shown++ >= 3) break;
+        snprintf(buf, sizeof buf, " batch %u: left %d ready %d evicting %d need %x launched %x", b.id, (int)r.queue_left[b.id], (int)b.ready, (int)b.evicting, b.need_mask, b.launched_mask);
+        out += buf;
+        for (int p = 0; p < r.K; p++) {
+            snprintf(buf, sizeof buf, " [p%d alive %u valid %d dry %d from %u]", p, r.pipes[p].alive[b.id], (int)r.pipes[p].alive_valid[b.id], (int)r.pipes[p].dry[b.id], b.from_it[p]);
+            out += buf;
+        }
+        out += ";";
+    }
+    return out;
+}
+
 // Is there room for another batch: a free batch id whose previous user's finish / resolve passes have COMPLETED (the
 // new batch's queue reset waits for them on the device; a reset that waits stalls every pipe behind it).
 bool wf_has_room(crt_ctx *c)
@@ -835,23 +933,28 @@ int wf_pump(crt_ctx *c, bool for_room)
 {
     WfRun &r = *c->run;
     const uint32_t max_ahead = (uint32_t)std::max(c->wf_ahead, c->wf_chunk + 1);   // iterations in flight per pipe before the driver waits
+    const double t_start = wf_now_ms();
     for (int guard = 0; guard < 4000000; guard++) {
+        if ((guard & 63) == 63 && wf_now_ms() - t_start > kWfStallMs) return fail(c, CRT_EDEVICE, "wavefront driver: pump stalled (%s)", wf_state(c).c_str());
         int rc = wf_poll_all(c);
         if (rc) return rc;
         if (for_room && wf_has_room(c)) return CRT_OK;
         unsigned long long backlog = 0, inflight = 0;
         for (const WfBatch &b : r.open)
             if (r.queue_left[b.id] && r.seg_total[b.id] > r.consumed[b.id]) backlog += r.seg_total[b.id] - r.consumed[b.id];
-        for (int p = 0; p < r.K; p++) inflight += r.pipes[p].it - r.pipes[p].it_confirmed;
+        uint32_t fl[crt_ctx::kMaxPipes];
+        for (int p = 0; p < r.K; p++) { fl[p] = wf_in_flight(c, p); inflight += fl[p]; }
         const double per_it = std::max(r.per_it, 1024.0);
         const double need = (double)backlog - per_it * (double)inflight * c->wf_feed;
         if (!(need > 0.0)) {
             if (!for_room) return CRT_OK;
             // nothing to feed, but the oldest batch has yet to retire: its last paths need iterations (or only its
             // finish / resolve passes are still running on the device)
+            if (wf_debug()) fprintf(stderr, "[pump %8.2f] no room and nothing to feed (open %zu)\n", wf_now_ms(), r.open.size());
             if (r.open.size() < (size_t)r.ring) {
                 const uint32_t id = (r.open.back().id + 1u) % r.ring;
                 HIPCHK(c, hipEventSynchronize(c->ev_resolved[id]));
+                r.resolved_recorded[id] = false;                 // (complete: nothing to wait for any more)
                 continue;
             }
             rc = wf_wait_progress(c);
@@ -860,18 +963,37 @@ int wf_pump(crt_ctx *c, bool for_room)
         }
         // the pipe with the fewest iterations in flight takes the next chunk
         int p = 0;
-        for (int q = 1; q < r.K; q++)
-            if (r.pipes[q].it - r.pipes[q].it_confirmed < r.pipes[p].it - r.pipes[p].it_confirmed) p = q;
+        for (int q = 1; q < r.K; q++) if (fl[q] < fl[p]) p = q;
         WfPipe &pp = r.pipes[p];
-        if (pp.it - pp.it_confirmed + (uint32_t)c->wf_chunk >= (uint32_t)kStatusRing - 1u || pp.it - pp.it_confirmed >= max_ahead) {
-            rc = wf_poll(c, p, true, nullptr);                  // back-pressure: wait for this pipe's oldest chunk
+        if (pp.it - pp.it_confirmed + (uint32_t)c->wf_chunk >= (uint32_t)kStatusRing - 1u) {
+            rc = wf_poll(c, p, true, nullptr);                  // (out of status slots: wait for this pipe's oldest record)
             if (rc) return rc;
             continue;
         }
+        if (fl[p] >= max_ahead) {                                // back-pressure: wait for this pipe's oldest iteration
+            const double t0 = wf_debug() ? wf_now_ms() : 0.0;
+            HIPCHK(c, hipEventSynchronize(c->ev_done[p][pp.it_done % kStatusRing]));
+            pp.it_done++;                                        // (known now, whatever a later hipEventQuery says)
+            if (wf_debug()) fprintf(stderr, "[pump %8.2f] waited %.2f ms for pipe %d (in flight %u %u, need %.0f, room %d)\n", wf_now_ms(), wf_now_ms() - t0, p, fl[0], fl[r.K - 1], need, (int)for_room);
+            continue;
+        }
+        // (a batch whose queue reset has not been seen complete is not listed yet: wait for it rather than launch
+        // iterations that cannot take its work)
+        {
+            bool listed = false;
+            WfBatch *pending = nullptr;
+            for (WfBatch &b : r.open) {
+                if (!r.queue_left[b.id]) continue;
+                if (wf_check_ready(c, b, false)) listed = true; else if (!pending) pending = &b;
+            }
+            if (!listed && pending && !wf_check_ready(c, *pending, true)) return fail(c, CRT_EDEVICE, "wavefront driver: queue reset failed");
+        }
         const double want = std::ceil(need / per_it / (double)r.K);
         const uint32_t iters = (uint32_t)std::min<double>((double)c->wf_chunk, std::max(1.0, want));
+        const double t0 = wf_debug() ? wf_now_ms() : 0.0;
         rc = wf_enqueue(c, p, iters);
         if (rc) return rc;
+        if (wf_debug()) fprintf(stderr, "[pump %8.2f] enqueued %u on pipe %d in %.3f ms (in flight %u %u, need %.0f, open %zu)\n", wf_now_ms(), iters, p, wf_now_ms() - t0, fl[0], fl[r.K - 1], need, r.open.size());
     }
     return fail(c, CRT_EDEVICE, "wavefront driver: pump did not converge");
 }
@@ -883,10 +1005,13 @@ int wf_finish_all(crt_ctx *c)
     const int K = r.K;
     const unsigned long long flush_at = std::min<unsigned long long>(c->wf_flush_at, kWfSideCap);
     for (int p = 0; p < K; p++) { r.pipes[p].done = false; r.pipes[p].chunk = (uint32_t)c->wf_chunk; }
+    for (WfBatch &b : r.open) if (!wf_check_ready(c, b, true)) return fail(c, CRT_EDEVICE, "wavefront driver: queue reset failed");
     r.all_evicting = false;
     int active = K;
+    const double t_start = wf_now_ms();
     for (unsigned long long guard = 0; active > 0; guard++) {
-        if (guard > 4000000ull) return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain");
+        if (guard > 4000000ull || ((guard & 15) == 15 && wf_now_ms() - t_start > 4.0 * kWfStallMs))
+            return fail(c, CRT_EDEVICE, "wavefront pipeline did not drain (%s)", wf_state(c).c_str());
         // one chunk is always enqueued AHEAD of the status being waited for, so the GPU never idles on the host
         // (iteration i's status record is written by the launch of iteration i + 1: three in flight = one ahead of the
         // one whose record is being waited for)
@@ -953,7 +1078,7 @@ int wf_finish_all(crt_ctx *c)
             WfParams F = r.pipes[0].W;
             F.tail_bound = c->wf_flush_ppw;
             // (a batch whose eviction began before the final one may hold up to a side pool's worth)
-            HIPCHK(c, wf_launch_finish(F, G, b.evicting ? kWfSideCap : (uint32_t)std::max<unsigned long long>(flush_at, 1), c->stream));
+            HIPCHK(c, wf_launch_finish(F, G, (uint32_t)std::max<unsigned long long>(std::max<unsigned long long>(flush_at, 1), b.evicting ? b.evict_bound : 0u), c->stream));
             c->last_launches++;
         }
         int rc = wf_resolve_batch(c, b);
@@ -1061,7 +1186,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         for (int p = 0; p < r.K; p++) {
             const uint32_t it0 = r.pipes[p].it + 2u * (uint32_t)kStatusRing;
             r.pipes[p] = WfPipe();
-            r.pipes[p].it = r.pipes[p].it_first = r.pipes[p].it_confirmed = it0;
+            r.pipes[p].it = r.pipes[p].it_first = r.pipes[p].it_confirmed = r.pipes[p].it_done = it0;
             r.pipes[p].chunk = (uint32_t)c->wf_chunk;
             WfParams &W = r.pipes[p].W;
             W.sc = c->sc;
@@ -1129,7 +1254,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         r.consumed[id] = 0;
         for (int p = 0; p < r.K; p++) {
             WfPipe &pp = r.pipes[p];
-            nb.from_it[p] = pp.it;
+            nb.from_it[p] = 0xFFFFFFFFu;                         // (set when the host sees the queue reset complete: wf_check_ready)
             pp.W.seg[id] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
             pp.W.n_samples = n;
             pp.W.batch_id = id; pp.W.keep_pool = 1;
@@ -1140,8 +1265,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         // This batch's queue and side counters are reset on a stream of their own, which waits only for what it must:
         // a launch still in flight that has the id's OLD queue in its list (enqueued while that held work; it would
         // take the new work with the old batch's parameters), and the finish / resolve passes of the batch that
-        // used the id before (they read its side pools and staging buffer).  The pipes wait for the reset, not for
-        // each other, and not for the straggler kernels on the context's stream.
+        // used the id before (they read its side pools and staging buffer).  No pipe waits for the reset: the queue is
+        // listed by the launches that are enqueued after the host has seen the reset complete.
         for (int p = 0; p < r.K; p++)
             if (r.listed_until[id][p] > r.pipes[p].it_confirmed) {
                 HIPCHK(c, hipEventRecord(c->ev_pub_join[p], r.pipes[p].stream));
@@ -1149,8 +1274,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             }
         if (r.resolved_recorded[id]) HIPCHK(c, hipStreamWaitEvent(c->pub_stream, c->ev_resolved[id], 0));
         for (int p = 0; p < r.K; p++) HIPCHK(c, wf_launch_init(r.pipes[p].W, c->pub_stream));   // (one block each)
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->pub_stream));
-        for (int p = 0; p < r.K; p++) HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
+        HIPCHK(c, hipEventRecord(c->ev_pub[id], c->pub_stream));
+        nb.ready = false;                                        // listed by the launches enqueued once the host has seen that event complete
         r.open.push_back(nb);
     }
     c->sample += n;
@@ -1215,16 +1340,26 @@ void crt_destroy(crt_ctx *c)
     c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
     c->w_vis.release(); c->w_list_ext.release(); c->w_tea.release(); c->w_wq.release();
     if (c->pub_stream) (void)hipStreamSynchronize(c->pub_stream);
+    for (int f = 0; f < crt_ctx::kFinishStreams; f++) {
+        if (c->fin_stream[f]) { (void)hipStreamSynchronize(c->fin_stream[f]); (void)hipStreamDestroy(c->fin_stream[f]); }
+        if (c->ev_fin[f]) (void)hipEventDestroy(c->ev_fin[f]);
+    }
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) {
         c->w_ctl[p].release();
         if (c->h_status[p]) (void)hipHostFree(c->h_status[p]);
-        for (int k = 0; k < crt_ctx::kStatusSlots; k++) if (c->ev_status[p][k]) (void)hipEventDestroy(c->ev_status[p][k]);
+        for (int k = 0; k < crt_ctx::kStatusSlots; k++) {
+            if (c->ev_status[p][k]) (void)hipEventDestroy(c->ev_status[p][k]);
+            if (c->ev_done[p][k]) (void)hipEventDestroy(c->ev_done[p][k]);
+        }
         if (c->pipe_stream[p]) (void)hipStreamDestroy(c->pipe_stream[p]);
         if (c->ev_join[p]) (void)hipEventDestroy(c->ev_join[p]);
         if (c->ev_pub_join[p]) (void)hipEventDestroy(c->ev_pub_join[p]);
         for (uint32_t b = 0; b < kWfRing; b++) if (c->ev_evict[p][b]) (void)hipEventDestroy(c->ev_evict[p][b]);
     }
-    for (uint32_t b = 0; b < kWfRing; b++) if (c->ev_resolved[b]) (void)hipEventDestroy(c->ev_resolved[b]);
+    for (uint32_t b = 0; b < kWfRing; b++) {
+        if (c->ev_resolved[b]) (void)hipEventDestroy(c->ev_resolved[b]);
+        if (c->ev_pub[b]) (void)hipEventDestroy(c->ev_pub[b]);
+    }
     if (c->pub_stream) (void)hipStreamDestroy(c->pub_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->h_dropped) (void)hipHostFree(c->h_dropped);

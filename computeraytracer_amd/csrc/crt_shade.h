@@ -230,6 +230,79 @@ __device__ __forceinline__ void traverse(const DevScene &S, int *stk, f3 o, f3 d
     }
 }
 
+// Single-ray walk of the quantised 4-wide tree (the nodes k_wf_trace walks: 64 bytes, 16-bit planes; same culling
+// arithmetic): less than half the dependent node fetches of the BVH2 walk above, which is what a lane of k_wf_finish
+// pays for -- a straggler's bounce is as long as its two walks.  Returns false when the LDS stack (kStackDepth
+// entries) would overflow: the caller repeats the ray with traverse(), whose stack need is bounded by the builders.
+template <bool COUNT>
+__device__ __forceinline__ bool traverse4q(const DevScene &S, int *stk, f3 o, f3 d, uint32_t exclude, bool anyhit,
+                                           float &t_max, uint32_t &b_index, uint32_t &b_slot, uint32_t &c_nodes, uint32_t &c_prims)
+{
+    const float t_min = 0.001f;
+    if (S.nprim == 0u) return true;
+    const float tiny = 1.0e-20f;
+    f3 id;
+    id.x = 1.0f / (abs_(d.x) > tiny ? d.x : __builtin_copysignf(tiny, d.x));
+    id.y = 1.0f / (abs_(d.y) > tiny ? d.y : __builtin_copysignf(tiny, d.y));
+    id.z = 1.0f / (abs_(d.z) > tiny ? d.z : __builtin_copysignf(tiny, d.z));
+    const bool gx = id.x < 0.0f, gy = id.y < 0.0f, gz = id.z < 0.0f;
+    // plane = qbase + q * qscale  =>  t = q * (qscale * id) + (qbase * id - o * id): one fma per plane
+    const f3 oid = f3{fma_(S.qbase[0], id.x, -(o.x * id.x)), fma_(S.qbase[1], id.y, -(o.y * id.y)), fma_(S.qbase[2], id.z, -(o.z * id.z))};
+    id = f3{S.qscale[0] * id.x, S.qscale[1] * id.y, S.qscale[2] * id.z};
+    const uint32_t b_slot_in = b_slot;
+    const float t_in = t_max;
+    const uint32_t i_in = b_index;
+    int sp = 0;
+    int node = S.root4;
+    for (;;) {
+        if (node >= 0) {
+            const uint4 *nq = S.nodes4q + 4 * (size_t)node;
+            const uint4 Q0 = nq[0], Q1 = nq[1], Q2 = nq[2], Q3 = nq[3];
+            const uint32_t nxa = gx ? Q1.z : Q0.x, nxb = gx ? Q1.w : Q0.y, fxa = gx ? Q0.x : Q1.z, fxb = gx ? Q0.y : Q1.w;
+            const uint32_t nya = gy ? Q2.x : Q0.z, nyb = gy ? Q2.y : Q0.w, fya = gy ? Q0.z : Q2.x, fyb = gy ? Q0.w : Q2.y;
+            const uint32_t nza = gz ? Q2.z : Q1.x, nzb = gz ? Q2.w : Q1.y, fza = gz ? Q1.x : Q2.z, fzb = gz ? Q1.y : Q2.w;
+            float k0, k1, k2, k3;
+#define CRT_QBOX1(K, NXQ, NYQ, NZQ, FXQ, FYQ, FZQ) { \
+                const float tn_ = __builtin_fmaxf(__builtin_fmaxf(fma_((float)(NXQ), id.x, oid.x), fma_((float)(NYQ), id.y, oid.y)), \
+                                                  __builtin_fmaxf(fma_((float)(NZQ), id.z, oid.z), t_min)); \
+                const float tf_ = __builtin_fminf(__builtin_fminf(fma_((float)(FXQ), id.x, oid.x), fma_((float)(FYQ), id.y, oid.y)), \
+                                                  __builtin_fminf(fma_((float)(FZQ), id.z, oid.z), t_max)); \
+                K = (tn_ <= tf_ * 1.0000005f) ? tn_ : 3.0e38f; }
+            CRT_QBOX1(k0, nxa & 0xFFFFu, nya & 0xFFFFu, nza & 0xFFFFu, fxa & 0xFFFFu, fya & 0xFFFFu, fza & 0xFFFFu)
+            CRT_QBOX1(k1, nxa >> 16, nya >> 16, nza >> 16, fxa >> 16, fya >> 16, fza >> 16)
+            CRT_QBOX1(k2, nxb & 0xFFFFu, nyb & 0xFFFFu, nzb & 0xFFFFu, fxb & 0xFFFFu, fyb & 0xFFFFu, fzb & 0xFFFFu)
+            CRT_QBOX1(k3, nxb >> 16, nyb >> 16, nzb >> 16, fxb >> 16, fyb >> 16, fzb >> 16)
+#undef CRT_QBOX1
+            int r0 = (int)Q3.x, r1 = (int)Q3.y, r2 = (int)Q3.z, r3 = (int)Q3.w;
+            if (COUNT) c_nodes += 4;
+#define CRT_CAS1(ka, ra, kb, rb) { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; kb = sw_ ? ka : kb; ka = tk_; \
+                                   const int tr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = tr_; }
+            CRT_CAS1(k0, r0, k1, r1) CRT_CAS1(k2, r2, k3, r3) CRT_CAS1(k0, r0, k2, r2) CRT_CAS1(k1, r1, k3, r3) CRT_CAS1(k1, r1, k2, r2)
+#undef CRT_CAS1
+            if (k0 < 3.0e38f) {
+                // descend into the nearest; the others wait on the stack, farthest pushed first
+                const int np = (k1 < 3.0e38f ? 1 : 0) + (k2 < 3.0e38f ? 1 : 0) + (k3 < 3.0e38f ? 1 : 0);
+                if (sp + np > kStackDepth) { t_max = t_in; b_index = i_in; b_slot = b_slot_in; return false; }
+                if (k3 < 3.0e38f) { stk[sp * 64] = r3; sp++; }
+                if (k2 < 3.0e38f) { stk[sp * 64] = r2; sp++; }
+                if (k1 < 3.0e38f) { stk[sp * 64] = r1; sp++; }
+                node = r0;
+                continue;
+            }
+        } else {
+            const uint32_t enc = ~(uint32_t)node;
+            const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++)
+                hit_test<false>(S, first + i, o, d, exclude, t_min, t_max, b_index, b_slot);
+            if (COUNT) c_prims += cnt;
+            if (anyhit && b_slot != b_slot_in) return true;
+        }
+        if (sp == 0) return true;
+        sp--;
+        node = stk[sp * 64];
+    }
+}
+
 // ---------------------------------------------------------------- shading helpers
 __device__ __forceinline__ f4 sample_spectrum(const DevScene &S, uint32_t index, const uint32_t l[4])
 {

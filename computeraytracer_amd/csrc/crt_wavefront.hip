@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFini
     // The rays these paths listed in their last pool iteration were traced there: start with the shade
     // step; from then on this lane traces what its own shade steps emit.
     bool pend_sh = false, pend_ext = false;
+    const bool wide = S.nodes4q != nullptr && S.nodes8q == nullptr;     // walk the quantised 4-wide tree when there is one
     ShadeCnt cn;
     uint32_t c_nodes = 0, c_prims = 0;
     for (int guard = 0; guard < 512 && __ballot(alive) != 0ull; guard++) {
@@ -1046,7 +1047,8 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFini
                 uint32_t b_index = P.vis[slot];                          // the light's primitive index
                 const uint32_t l_slot = S.slot_of_index[b_index];
                 uint32_t b_slot = l_slot;
-                traverse<COUNT>(S, stk, o, xyz(sd), excl, true, t_max, b_index, b_slot, c_nodes, c_prims);
+                if (!wide || !traverse4q<COUNT>(S, stk, o, xyz(sd), excl, true, t_max, b_index, b_slot, c_nodes, c_prims))
+                    traverse<COUNT>(S, stk, o, xyz(sd), excl, true, t_max, b_index, b_slot, c_nodes, c_prims);
                 P.vis[slot] = (b_slot == l_slot) ? 1u : 0u;
             }
             if (pend_ext) {
@@ -1054,7 +1056,8 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFini
                 if (f_bits(rd.w) == 0u) {                                // (else: non-finite ray, resolved by the shade step)
                     float t_max = CRT_INFINITY;
                     uint32_t b_index = kNoHit, b_slot = kNoHit;
-                    traverse<COUNT>(S, stk, o, xyz(rd), excl, false, t_max, b_index, b_slot, c_nodes, c_prims);
+                    if (!wide || !traverse4q<COUNT>(S, stk, o, xyz(rd), excl, false, t_max, b_index, b_slot, c_nodes, c_prims))
+                        traverse<COUNT>(S, stk, o, xyz(rd), excl, false, t_max, b_index, b_slot, c_nodes, c_prims);
                     P.hit[slot] = float2{t_max, bits_f(b_slot)};
                 }
             }

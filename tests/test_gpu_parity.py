@@ -422,7 +422,7 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
     renderer.upload(ps).build_accel("bvh2")
     try:
         for epoch in range(int(os.environ.get("CRT_TEST_EPOCHS", "8"))):
-            opts = {"wf_pool": int(rng.choice([0, 1 << 18, 1 << 19])), "wf_pipes": int(rng.choice([1, 2])),
+            opts = {"wf_pool": int(rng.choice([0, 1 << 18, 1 << 19])), "wf_pipes": int(rng.choice([1, 2, 2, 3, 4])),
                     "wf_chunk": int(rng.choice([1, 2, 4])), "wf_feed_pct": int(rng.choice([50, 100, 200])),
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
                     "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0])),
@@ -454,7 +454,7 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             assert renderer.sample == total
     finally:
         for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 1, "wf_feed_pct": 100, "wf_finish_at": 32768, "wf_ahead": 3,
-                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 2}.items():
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 4}.items():
             renderer.set_option(k, v)
 
 

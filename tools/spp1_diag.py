@@ -27,7 +27,7 @@ for spp in (1, 4):
         for k, v in opts.items(): r.set_option(k, v)
         a, h = t(spp)
         out.append('%s: %.2f (host %.2f)' % (','.join('%s=%d' % kv for kv in opts.items()) or 'default', a, h))
-        for k, v in {'wf_pool': 0, 'wf_pipes': 2, 'wf_chunk': 1, 'wf_finish_at': 32768, 'wf_feed_pct': 100, 'wf_pool_spp': 2, 'wf_ring': 32, 'wf_ahead': 3, 'wf_side_ppw': 64}.items(): r.set_option(k, v)
+        for k, v in {'wf_pool': 0, 'wf_pipes': 2, 'wf_chunk': 1, 'wf_finish_at': 32768, 'wf_feed_pct': 100, 'wf_pool_spp': 4, 'wf_ring': 32, 'wf_ahead': 3, 'wf_side_ppw': 64}.items(): r.set_option(k, v)
     print(name, spp, 'spp |', ' | '.join(out), flush=True)
 
 r.reset()
