@@ -39,6 +39,22 @@ def main():
     ap.add_argument("--cpu-crop", default="256x144", help="oracle sample: centre crop WxH at 1 spp")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: start the N rank processes (one per GPU) before anything in THIS process
+        # touches the GPU, relay rank 0's JSON line and the exit code.  (Never exec from a process that has
+        # initialised HIP; a child process is fine.)
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -47,8 +63,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     # CRT_BENCH_BACKEND=gloo + CRT_BENCH_ONE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all
     # ranks share cuda:0, strips gathered through host memory).  The measured configuration is RCCL.
     backend = os.environ.get("CRT_BENCH_BACKEND", "nccl")
@@ -67,6 +82,21 @@ def main():
     from computeraytracer_amd import Renderer, scenes_synth
     from computeraytracer_amd.distributed import StripFrame
 
+    class HostStagedStripFrame(StripFrame):
+        """Rehearsal only (CRT_BENCH_BACKEND=gloo): gloo has no device all_gather, so the strips go through host
+        memory.  The measured configuration is StripFrame's own gather: one RCCL all_gather_into_tensor."""
+
+        def gather(self, accum: bool = True):
+            if self.world == 1:
+                return
+            if accum:
+                out = torch.empty(self.full_accum.shape, dtype=self.full_accum.dtype)
+                dist.all_gather_into_tensor(out, self.accum.cpu())
+                self.full_accum.copy_(out)
+            out = torch.empty(self.full_rgba.shape, dtype=self.full_rgba.dtype)
+            dist.all_gather_into_tensor(out, self.rgba.cpu())
+            self.full_rgba.copy_(out)
+
     W, H = args.width, args.height
     if args.scene == "soup":
         ps = scenes_synth.soup(args.soup_tris, W, H)
@@ -80,7 +110,7 @@ def main():
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
     r.upload(ps)
-    sf = StripFrame(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
+    sf = (HostStagedStripFrame if backend != "nccl" else StripFrame)(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
     sf.apply(r)
     t0 = time.time()
     r.build_accel("bvh2")
@@ -160,6 +190,21 @@ def main():
     r.sync()
     c = r.counters()
     r.enable_counters(False)
+    # SURVEY 8(d)'s canonical accounting prices a ray by the boxes a BVH2 walk tests (32 B each: 2 x vec3 + 2 x u32
+    # per node).  Counted with the single-kernel form, which walks the BVH2 itself, on the first sample of the timed
+    # range (per-ray counts are a property of the scene and the sample; the timed kernels walk the 4-wide tree).
+    canon = None
+    if rank == 0:
+        r.set_option("pipeline", 0)
+        r.reset()
+        r.write_accum(np.zeros((sf.local_rows, W, 4), np.float32), args.warmup * args.spp)
+        r.enable_counters(True).reset_counters()
+        r.frame(1).sync()
+        c2 = r.counters()
+        r.enable_counters(False)
+        r.set_option("pipeline", 1)
+        canon = (32.0 * c2["nodes"] + 48.0 * c2["prims"] + 16.0 * c2["hits"] + 36.0 * c2["paths"]) / max(c2["rays"], 1)
+        canon_counts = (c2["nodes"] / max(c2["rays"], 1), c2["prims"] / max(c2["rays"], 1))
     cnt = torch.tensor([c["rays"], c["nodes"], c["prims"], c["hits"], c["paths"], c["shadow"], c["walked"]], dtype=torch.float64, device=dev)
     mine = cnt.clone()
     if world > 1:
@@ -179,11 +224,14 @@ def main():
         avg_ms = kernel_ms / max(launches, 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         whole_pass = alg_bytes / (total_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes of this exact workload (a bench run cannot profile
+        # itself: rocprofv3 --pmc serialises the kernels): reported only while the kernel sources are the ones it was
+        # measured on, null otherwise.
         traffic, traffic_src = None, None
-        try:    # HBM bytes per launch from the committed PMC passes of this exact workload (a bench run cannot profile itself)
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
                 tj = json.load(f)
-            if tj["workload"] == f"{args.scene} {W}x{H} {args.spp}spp n_gpus={world}":
+            if tj["workload"] == f"{args.scene} {W}x{H} {args.spp}spp n_gpus={world}" and tj.get("kernel_sources_sha256") == kernel_sources_sha256():
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
         except (OSError, KeyError, ValueError):
             pass
@@ -220,7 +268,15 @@ def main():
                          "kernel_share_of_pass": round(kernel_ms / max(total_ms, 1e-9), 3),
                          "note": "two half-pool pipes run on two streams, so two k_wf_trace launches (and a k_wf_shade) overlap: "
                                  "summed launch durations exceed the wall time of the pass; whole_pass_* = bytes / wall time",
-                         "whole_pass_GBs": round(whole_pass, 1), "whole_pass_frac": round(whole_pass / HBM_PEAK_GBS, 5)},
+                         "whole_pass_GBs": round(whole_pass, 1), "whole_pass_frac": round(whole_pass / HBM_PEAK_GBS, 5),
+                         "accounting": "this build's records: 16 B per child box of a 64-byte quantised 4-wide node + 48 B per primitive "
+                                       "+ 16 B per hit + 36 B per path (conservative: fewer bytes than the canonical form)",
+                         "canonical": {"what": "SURVEY 8(d) / BASELINE.md: 32 B per BVH2 box tested + 48 B per primitive + 16 B per hit + 36 B per path, "
+                                               "per-ray counts of the BVH2 walk (single-kernel form) on the first timed sample",
+                                       "bytes_per_ray": round(canon, 1), "boxes_per_ray": round(canon_counts[0], 2), "prims_per_ray": round(canon_counts[1], 2),
+                                       "achieved": round(canon * m_rays / (kernel_ms * 1e-3) / 1e9, 2),
+                                       "frac": round(canon * m_rays / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                       "whole_pass_frac": round(canon * m_rays / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ps, args)
@@ -229,6 +285,18 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     r.close()
+
+
+def kernel_sources_sha256():
+    """Hash of the device sources the PMC traffic figure was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "computeraytracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
 def cpu_baseline(ps, args):

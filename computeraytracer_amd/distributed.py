@@ -56,17 +56,9 @@ class StripFrame:
         """all_gather of the strips: the rgba8 framebuffer always (what the reference's frame()
         produces for display), the f32 XYZ accumulator on request (checkpoint / final readout)."""
         if self.world > 1:
-            if dist.get_backend() == "gloo" and self.accum.is_cuda:
-                # functional fallback for boxes without one GPU per rank (tests / rehearsal): stage
-                # through host memory, because gloo has no device all_gather.  RCCL is the real path.
-                if accum:
-                    out = torch.empty(self.full_accum.shape, dtype=self.full_accum.dtype)
-                    dist.all_gather_into_tensor(out, self.accum.cpu())
-                    self.full_accum.copy_(out)
-                out = torch.empty(self.full_rgba.shape, dtype=self.full_rgba.dtype)
-                dist.all_gather_into_tensor(out, self.rgba.cpu())
-                self.full_rgba.copy_(out)
-                return
+            if self.accum.is_cuda and dist.get_backend() != "nccl":
+                raise RuntimeError("StripFrame.gather: device strips need the nccl (RCCL) backend; backend is "
+                                   f"{dist.get_backend()!r} (rehearsals on a one-GPU box stage through the host themselves)")
             if accum:
                 dist.all_gather_into_tensor(self.full_accum, self.accum)
             dist.all_gather_into_tensor(self.full_rgba, self.rgba)

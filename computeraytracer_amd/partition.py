@@ -17,23 +17,6 @@ def strip_rows(height: int, world: int, rank: int) -> tuple[int, int]:
     return y0, min(y0 + per, height)
 
 
-def assemble(strips, height: int):
-    """Concatenate gathered (padded) strips [world, rows_max, W, C] back into [H, W, C]."""
-    world = strips.shape[0]
-    parts = []
-    for r in range(world):
-        y0, y1 = strip_rows(height, world, r)
-        parts.append(strips[r, : y1 - y0])
-    import numpy as np
-    try:
-        import torch
-        if isinstance(strips, torch.Tensor):
-            return torch.cat(parts, 0)
-    except ImportError:
-        pass
-    return np.concatenate(parts, 0)
-
-
 def band_rows(height: int, world: int, rank: int, band: int = 8):
     """Global row indices of rank `rank` under the row-interleaved partition (bands of `band`
     rows dealt round-robin): rows y with (y // band) % world == rank, in local order."""
