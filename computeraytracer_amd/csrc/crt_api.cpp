@@ -34,6 +34,8 @@ hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks
 hipError_t wf_launch_finish(const WfParams &P, WfFinishSegs G, uint32_t max_paths, hipStream_t s);
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
 hipError_t build_lbvh(const float *lo, const float *hi, uint32_t n, Bvh &out, hipStream_t stream);
+hipError_t build_lbvh_device(const unsigned char *d_raw, uint32_t n, float hit_pad, float4 *d_prim, float4 *d_primD,
+                             uint32_t *d_slot_of_index, float *d_nodes2, uint4 *d_nodes4q, LbvhDeviceResult &res, hipStream_t stream);
 }  // namespace crt
 
 using namespace crt;
@@ -112,6 +114,7 @@ struct crt_ctx {
     int wf_width = 4;               // node width of the wavefront traversal: 4 (64-byte quantised nodes), or 8 (128-byte; measured slower)
 
     // device scene
+    DevBuf<unsigned char> d_raw;    // the scene's 80-byte records as uploaded (input of the all-device LBVH build)
     DevBuf<float4> d_prim, d_primD, d_nodes, d_nodes4, d_lights;
     DevBuf<int> w_overflow;
     DevBuf<uint4> d_nodes4q, d_nodes8q;
@@ -275,11 +278,53 @@ void camera_frame(const float cam[16], float out[12])
     out[9] = eye.x; out[10] = eye.y; out[11] = eye.z;
 }
 
+// crt_build_accel(CRT_ACCEL_LBVH), all on the device (crt_lbvh.hip): bounds, Morton order, hierarchy, collapse to the
+// 4-wide tree, quantisation and the leaf-ordered primitive records; nothing of the tree visits the host.  Returns
+// CRT_OK with *done = false when the scene cannot take this path (not quantisable): the caller builds the host way.
+int build_accel_on_device(crt_ctx *c, bool *done)
+{
+    *done = false;
+    const uint32_t n = (uint32_t)c->prims.size();
+    if (n < 2 || !c->quantize || c->wf_width != 4 || c->d_raw.n < (size_t)n * 80) return CRT_OK;
+    HIPCHK(c, c->d_prim.alloc((size_t)n * 3));
+    HIPCHK(c, c->d_primD.alloc(n));
+    HIPCHK(c, c->d_slot_of_index.alloc(n));
+    HIPCHK(c, c->d_nodes.alloc((size_t)(n - 1) * 4));
+    HIPCHK(c, c->d_nodes4q.alloc((size_t)(n - 1) * 4));
+    HIPCHK(c, c->d_nodes4.alloc(8));
+    LbvhDeviceResult res;
+    const hipError_t e = build_lbvh_device(c->d_raw.p, n, c->sc.hit_pad, c->d_prim.p, c->d_primD.p, c->d_slot_of_index.p,
+                                           (float *)c->d_nodes.p, c->d_nodes4q.p, res, c->stream);
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? CRT_ENOMEM : CRT_EDEVICE, "crt_build_accel: GPU LBVH build: %s", hipGetErrorString(e));
+    if (!res.quantised) return CRT_OK;
+    // the host keeps the tree's statistics only
+    c->bvh = Bvh(); c->bvh4 = Bvh4(); c->bvh4q = Bvh4Q(); c->bvh8q = Bvh8Q();
+    c->bvh.root = 0; c->bvh.n_inner = n - 1; c->bvh.n_leaves = n; c->bvh.max_depth = res.max_depth;
+    c->bvh4.root = 0; c->bvh4.n_inner = res.n_nodes4;
+    c->bvh4q.ok = true;
+    for (int a = 0; a < 3; a++) { c->bvh4q.base[a] = res.qbase[a]; c->bvh4q.scale[a] = res.qscale[a]; c->sc.qbase[a] = res.qbase[a]; c->sc.qscale[a] = res.qscale[a]; }
+    c->accel_builder = 1;
+    c->sc.prim = c->d_prim.p; c->sc.primD = c->d_primD.p; c->sc.slot_of_index = c->d_slot_of_index.p;
+    c->sc.nodes = c->d_nodes.p; c->sc.root = 0;
+    c->sc.nodes4 = c->d_nodes4.p; c->sc.root4 = 0; c->sc.n_nodes4 = res.n_nodes4;
+    c->sc.nodes4q = c->d_nodes4q.p;
+    c->sc.nodes8q = nullptr; c->sc.root8 = -1;
+    c->sc.nprim = n;
+    c->accel_mode = CRT_ACCEL_BVH2;
+    *done = true;
+    return CRT_OK;
+}
+
 // Builds the device primitive arrays in `order` and (for BVH2) the node array.
 int upload_geometry(crt_ctx *c, int mode)
 {
     const uint32_t n = (uint32_t)c->prims.size();
     const float pad = c->sc.hit_pad;
+    if (mode == CRT_ACCEL_BVH2 && c->want_lbvh) {
+        bool done = false;
+        int rc = build_accel_on_device(c, &done);
+        if (rc || done) return rc;
+    }
     std::vector<uint32_t> order;
     c->bvh = Bvh();
     if (mode == CRT_ACCEL_BVH2 && n > 0) {
@@ -1333,7 +1378,7 @@ void crt_destroy(crt_ctx *c)
     for (int p = 0; p < crt_ctx::kMaxPipes; p++) if (c->pipe_stream[p]) (void)hipStreamSynchronize(c->pipe_stream[p]);
 
     delete c->run;
-    c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_nodes8q.release(); c->d_lights.release(); c->w_overflow.release();
+    c->d_raw.release(); c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_nodes8q.release(); c->d_lights.release(); c->w_overflow.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
@@ -1423,6 +1468,8 @@ int crt_upload_scene(crt_ctx *c, const void *primitives, size_t nprim, const voi
         if (c->prims[i].category != 2u) (S.nf_last[0] == kNoHit ? S.nf_last[0] : S.nf_last[1]) = (uint32_t)i;
     camera_frame(c->camera, S.cam);
 
+    HIPCHK(c, c->d_raw.alloc(std::max<size_t>(nprim * 80, 16)));
+    if (nprim) HIPCHK(c, hipMemcpy(c->d_raw.p, primitives, nprim * 80, hipMemcpyHostToDevice));
     HIPCHK(c, c->d_spectra.alloc(nspectra * kNLambda));
     HIPCHK(c, hipMemcpy(c->d_spectra.p, spectra, nspectra * kNLambda * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(c, c->d_cie.alloc(3 * kNCie));

@@ -68,4 +68,12 @@ struct Bvh8Q {
 };
 void build_bvh8q(const Bvh &b2, Bvh8Q &out);
 
+// Result of the all-device LBVH build (crt_lbvh.hip build_lbvh_device): the arrays themselves stay on the device.
+struct LbvhDeviceResult {
+    uint32_t n_nodes4 = 0;         // 4-wide nodes written (breadth-first numbering, root = 0)
+    uint32_t max_depth = 0;        // of the BVH2
+    float qbase[3] = {0, 0, 0}, qscale[3] = {1, 1, 1};
+    bool quantised = false;        // false: the scene cannot be quantised (quantize_bvh4's rules); use the host path
+};
+
 }  // namespace crt
