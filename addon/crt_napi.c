@@ -40,25 +40,46 @@ static napi_value throw_crt(napi_env env, crt_ctx *ctx, int code, const char *wh
         if (rc_ != CRT_OK) return throw_crt((env), (ctx), rc_, (what));  \
     } while (0)
 
+/* What a handle holds: the context and the queue of asynchronous jobs on it.  The C ABI allows one thread per
+ * context at a time, so the *Async entry points run their jobs one after the other (napi_async_work on the libuv
+ * pool, the next one queued when the previous completes) and the synchronous entry points refuse to run while
+ * jobs are pending ("await the promises first"). */
+struct job;
+typedef struct slot {
+    crt_ctx *ctx;
+    struct job *head, *tail;     /* pending jobs, head = the one running */
+} slot;
+
 static void finalize_ctx(napi_env env, void *data, void *hint)
 {
     (void)env; (void)hint;
-    crt_ctx **slot = (crt_ctx **)data;
-    if (slot) {
-        if (*slot) crt_destroy(*slot);
-        free(slot);
+    slot *s = (slot *)data;
+    if (s) {
+        if (s->ctx && !s->head) crt_destroy(s->ctx);   /* (a job still running keeps the context alive; leaked at exit) */
+        free(s);
     }
 }
 
-/* args[0] is always the handle (an external holding crt_ctx**) */
-static crt_ctx *get_ctx(napi_env env, napi_value v)
+static slot *get_slot(napi_env env, napi_value v)
 {
     void *p = NULL;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*(crt_ctx **)p) {
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((slot *)p)->ctx) {
         napi_throw_type_error(env, NULL, "invalid or destroyed crt context handle");
         return NULL;
     }
-    return *(crt_ctx **)p;
+    return (slot *)p;
+}
+
+/* args[0] is always the handle (an external holding a slot); synchronous calls need an idle context */
+static crt_ctx *get_ctx(napi_env env, napi_value v)
+{
+    slot *s = get_slot(env, v);
+    if (!s) return NULL;
+    if (s->head) {
+        napi_throw_error(env, "ERR_CRT_BUSY", "asynchronous calls are pending on this context: await their promises first");
+        return NULL;
+    }
+    return s->ctx;
 }
 
 /* Bytes of an ArrayBuffer / TypedArray / DataView / Buffer argument. */
@@ -104,10 +125,10 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     crt_ctx *ctx = NULL;
     int rc = crt_create(&ctx, dev);
     if (rc != CRT_OK) return throw_crt(env, NULL, rc, "crt_create");
-    crt_ctx **slot = (crt_ctx **)malloc(sizeof *slot);
-    *slot = ctx;
+    slot *sl = (slot *)calloc(1, sizeof *sl);
+    sl->ctx = ctx;
     napi_value ext;
-    NAPI_OK(env, napi_create_external(env, slot, finalize_ctx, NULL, &ext));
+    NAPI_OK(env, napi_create_external(env, sl, finalize_ctx, NULL, &ext));
     return ext;
 }
 
@@ -115,9 +136,13 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
 {
     ARGS(1)
     void *p = NULL;
-    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && *(crt_ctx **)p) {
-        crt_destroy(*(crt_ctx **)p);
-        *(crt_ctx **)p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && ((slot *)p)->ctx) {
+        if (((slot *)p)->head) {
+            napi_throw_error(env, "ERR_CRT_BUSY", "destroy: asynchronous calls are pending on this context");
+            return NULL;
+        }
+        crt_destroy(((slot *)p)->ctx);
+        ((slot *)p)->ctx = NULL;
     }
     return undefined(env);
 }
@@ -345,6 +370,108 @@ static napi_value js_set_option(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+/* ------------------------------------------------------------------ asynchronous entry points
+ * traceAsync(h, n), syncAsync(h), readRgba8Async(h), readAccumAsync(h) -> Promise.  The reference's frame() is
+ * fire-and-forget (queue.submit, src/main.js:618-620): a Node display loop must not block its event loop on the
+ * GPU either.  Jobs of one context run in call order. */
+enum { JOB_TRACE, JOB_SYNC, JOB_READ_RGBA8, JOB_READ_ACCUM };
+typedef struct job {
+    napi_async_work work;
+    napi_deferred deferred;
+    slot *sl;
+    int op, rc;
+    uint32_t n, px;
+    void *data;              /* ArrayBuffer memory of a read job (kept alive by ab_ref) */
+    napi_ref ab_ref;
+    char err[640];
+    struct job *next;
+} job;
+
+static void job_execute(napi_env env, void *data)
+{
+    (void)env;
+    job *j = (job *)data;
+    crt_ctx *ctx = j->sl->ctx;
+    switch (j->op) {
+    case JOB_TRACE: j->rc = crt_trace(ctx, j->n); break;
+    case JOB_SYNC: j->rc = crt_sync(ctx); break;
+    case JOB_READ_RGBA8: j->rc = crt_read_rgba8(ctx, (uint8_t *)j->data); break;
+    default: j->rc = crt_read_accum(ctx, (float *)j->data); break;
+    }
+    if (j->rc != CRT_OK) {
+        const char *d = crt_last_error(ctx);
+        snprintf(j->err, sizeof j->err, "asynchronous call failed (%d): %s", j->rc, d ? d : "");
+    }
+}
+
+static void job_complete(napi_env env, napi_status status, void *data)
+{
+    job *j = (job *)data;
+    slot *sl = j->sl;
+    napi_value result = NULL;
+    if (status != napi_ok && j->rc == CRT_OK) { j->rc = CRT_EDEVICE; snprintf(j->err, sizeof j->err, "asynchronous call cancelled"); }
+    if (j->rc == CRT_OK) {
+        if (j->op == JOB_READ_RGBA8 || j->op == JOB_READ_ACCUM) {
+            napi_value ab;
+            if (napi_get_reference_value(env, j->ab_ref, &ab) == napi_ok)
+                napi_create_typedarray(env, j->op == JOB_READ_RGBA8 ? napi_uint8_array : napi_float32_array, (size_t)j->px * 4, ab, 0, &result);
+        }
+        if (!result) napi_get_undefined(env, &result);
+        napi_resolve_deferred(env, j->deferred, result);
+    } else {
+        napi_value msg, code, errv;
+        napi_create_string_utf8(env, j->err, NAPI_AUTO_LENGTH, &msg);
+        napi_create_string_utf8(env, "ERR_CRT", NAPI_AUTO_LENGTH, &code);
+        napi_create_error(env, code, msg, &errv);
+        napi_reject_deferred(env, j->deferred, errv);
+    }
+    if (j->ab_ref) napi_delete_reference(env, j->ab_ref);
+    napi_delete_async_work(env, j->work);
+    /* the next job of this context */
+    sl->head = j->next;
+    if (!sl->head) sl->tail = NULL;
+    else napi_queue_async_work(env, sl->head->work);
+    free(j);
+}
+
+static napi_value start_job(napi_env env, napi_callback_info info, int op)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < (op == JOB_TRACE ? 2u : 1u)) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
+    slot *sl = get_slot(env, argv[0]);
+    if (!sl) return NULL;
+    job *j = (job *)calloc(1, sizeof *j);
+    j->sl = sl; j->op = op;
+    if (op == JOB_TRACE) {
+        if (napi_get_value_uint32(env, argv[1], &j->n) != napi_ok) { free(j); napi_throw_type_error(env, NULL, "traceAsync: sample count expected"); return NULL; }
+    }
+    if (op == JOB_READ_RGBA8 || op == JOB_READ_ACCUM) {
+        uint32_t t[4];
+        if (crt_tile(sl->ctx, t) != CRT_OK) { free(j); return throw_crt(env, sl->ctx, CRT_ESTATE, "crt_tile"); }
+        j->px = t[2] * t[3];
+        napi_value ab;
+        if (napi_create_arraybuffer(env, (size_t)j->px * (op == JOB_READ_RGBA8 ? 4 : 16), &j->data, &ab) != napi_ok ||
+            napi_create_reference(env, ab, 1, &j->ab_ref) != napi_ok) { free(j); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    }
+    napi_value promise, name;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "crt_async", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, job_execute, job_complete, j, &j->work) != napi_ok) {
+        free(j);
+        napi_throw_error(env, NULL, "crt_napi: could not create the asynchronous job");
+        return NULL;
+    }
+    if (sl->tail) { sl->tail->next = j; sl->tail = j; }
+    else { sl->head = sl->tail = j; napi_queue_async_work(env, j->work); }
+    return promise;
+}
+static napi_value js_trace_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_TRACE); }
+static napi_value js_sync_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_SYNC); }
+static napi_value js_read_rgba8_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_RGBA8); }
+static napi_value js_read_accum_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_ACCUM); }
+
 static napi_value js_abi_version(napi_env env, napi_callback_info info)
 {
     (void)info;
@@ -363,6 +490,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"enableCounters", js_enable_counters}, {"resetCounters", js_reset_counters},
         {"counters", js_counters}, {"accelStats", js_accel_stats}, {"lastTraceMs", js_last_trace_ms},
         {"setOption", js_set_option}, {"abiVersion", js_abi_version},
+        {"traceAsync", js_trace_async}, {"syncAsync", js_sync_async},
+        {"readRgba8Async", js_read_rgba8_async}, {"readAccumAsync", js_read_accum_async},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -46,6 +46,13 @@ function Main(options = {}) {
 
   return {
     width, height, packed, device, frame, run,
+    // Promise forms: the job runs on a worker thread, the event loop stays free (the reference's frame() is
+    // fire-and-forget too: queue.submit, src/main.js:618-620).  Jobs of one device run in call order; the blocking
+    // calls throw ERR_CRT_BUSY while any are pending.
+    frameAsync: (n = 1) => a.traceAsync(device, n),
+    syncAsync: () => a.syncAsync(device),
+    readRgba8Async: () => a.readRgba8Async(device),
+    readAccumAsync: () => a.readAccumAsync(device),
     sync: () => a.sync(device),
     reset: () => a.reset(device),
     get sample() { return a.sampleCount(device); },

@@ -53,6 +53,15 @@ typedef struct { float x, y, z; } v3;
 typedef struct { float x, y, z, w; } v4;
 
 static inline float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+/* Sensitivity variants (oracle/Makefile `variants`, oracle/sensitivity.py): other CONFORMANT WGSL evaluations of the
+ * same shader, to measure how far a real WebGPU stack may sit from the pinned contract.  Never used by the tests'
+ * parity checks.  ORC_VARIANT_UNFUSED: dot / cross / ray_at as separate multiplies and adds, left to right.
+ * ORC_VARIANT_LIBM: sin cos tan exp pow from libm instead of the fixed kernels. */
+#ifdef ORC_VARIANT_UNFUSED
+static inline float gfma_(float a, float b, float c) { float p = a * b; return p + c; }
+#else
+static inline float gfma_(float a, float b, float c) { return fmaf(a, b, c); }
+#endif
 static inline float max_(float a, float b) { return (a < b) ? b : a; }
 static inline float min_(float a, float b) { return (b < a) ? b : a; }
 static inline float abs_(float a) { return fabsf(a); }
@@ -63,10 +72,10 @@ static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); 
 static inline v3 mul3s(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 static inline v3 div3s(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
 static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
-static inline float dot3(v3 a, v3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+static inline float dot3(v3 a, v3 b) { return gfma_(a.z, b.z, gfma_(a.y, b.y, a.x * b.x)); }
 static inline v3 cross3(v3 a, v3 b) {
-    return V3(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)),
-              fma_(a.x, b.y, -(a.y * b.x)));
+    return V3(gfma_(a.y, b.z, -(a.z * b.y)), gfma_(a.z, b.x, -(a.x * b.z)),
+              gfma_(a.x, b.y, -(a.y * b.x)));
 }
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
 static inline v3 normalize3(v3 a) { return div3s(a, length3(a)); }
@@ -77,7 +86,7 @@ static inline v4 mul4s(v4 a, float s) { return V4(a.x * s, a.y * s, a.z * s, a.w
 static inline v4 div4s(v4 a, float s) { return V4(a.x / s, a.y / s, a.z / s, a.w / s); }
 static inline v4 add4(v4 a, v4 b) { return V4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 static inline float dot4(v4 a, v4 b) {
-    return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)));
+    return gfma_(a.w, b.w, gfma_(a.z, b.z, gfma_(a.y, b.y, a.x * b.x)));
 }
 
 /* ------------------------------------------------------- deterministic math */
@@ -87,7 +96,7 @@ static inline float pow2i(int n) { return bits_f((uint32_t)(n + 127) << 23); } /
 
 /* sin & cos, x >= 0 (the live path only evaluates [0, 2*pi], CS:755-757, and
  * fov/2, CS:479).  3-term Cody-Waite reduction to [-pi/4,pi/4], Cephes kernels. */
-static void sincos_(float x, float *s, float *c)
+static __attribute__((unused)) void sincos_(float x, float *s, float *c)
 {
     float kf = floorf(fma_(x, 0.63661977236758134f, 0.5f));
     int k = (int)kf;
@@ -107,12 +116,23 @@ static void sincos_(float x, float *s, float *c)
     default: *s = -cp; *c = sp; break;
     }
 }
+#ifdef ORC_VARIANT_LIBM
+static void sincos_libm_(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
+#define sincos_ sincos_libm_
+static float sin_(float x) { return sinf(x); }
+static float cos_(float x) { return cosf(x); }
+static float tan_(float x) { return tanf(x); }
+#else
 static float sin_(float x) { float s, c; sincos_(x, &s, &c); return s; }
 static float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
 static float tan_(float x) { float s, c; sincos_(x, &s, &c); return s / c; }
+#endif
 
 static float exp_(float x)
 {
+#ifdef ORC_VARIANT_LIBM
+    return expf(x);
+#endif
     if (x != x) return x;
     if (x > 88.7228394f) return bits_f(0x7F800000u);
     if (x < -103.972084f) return 0.0f;
@@ -177,6 +197,9 @@ static float exp2_(float x)
 /* WGSL pow(x,y) is specified as exp2(y*log2(x)); that is what this is. */
 static float pow_(float x, float y)
 {
+#ifdef ORC_VARIANT_LIBM
+    return powf(x, y);
+#endif
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : bits_f(0x7F800000u);
     return exp2_(y * log2_(x));
 }
@@ -342,8 +365,8 @@ static void ray_intersection(const prim_t *pr, const ray_t *ray, isect_ctx *ctx,
         v3 oo = sub3(pr->data1, origin);
         float t = dot3(normal, oo) / ndotd;                  /* CS:554 */
         if (t < ctx->t_min || t > ctx->t_max) return;        /* CS:557 (tie: later wins, Q4) */
-        v3 p = V3(fma_(t, direction.x, origin.x), fma_(t, direction.y, origin.y),
-                  fma_(t, direction.z, origin.z));           /* CS:561 ray_at */
+        v3 p = V3(gfma_(t, direction.x, origin.x), gfma_(t, direction.y, origin.y),
+                  gfma_(t, direction.z, origin.z));          /* CS:561 ray_at */
         v3 m = sub3(p, pr->data1);
         float u = dot3(m, edge1) / dot3(edge1, edge1);       /* CS:563 */
         float v = dot3(m, edge2) / dot3(edge2, edge2);       /* CS:564 */
@@ -373,8 +396,8 @@ static void ray_intersection(const prim_t *pr, const ray_t *ray, isect_ctx *ctx,
             t = (-b + sq) / (2.0f * a);
             if (t < ctx->t_min || t > ctx->t_max) return;
         }
-        v3 p = V3(fma_(t, direction.x, origin.x), fma_(t, direction.y, origin.y),
-                  fma_(t, direction.z, origin.z));
+        v3 p = V3(gfma_(t, direction.x, origin.x), gfma_(t, direction.y, origin.y),
+                  gfma_(t, direction.z, origin.z));
         v3 normal = normalize3(sub3(p, center));             /* CS:618 outward always (Q6) */
         si->position = p; si->normal = normal;
         si->emission_index = pr->emission; si->reflectance_index = pr->reflectance;
@@ -403,7 +426,7 @@ static void ray_intersection(const prim_t *pr, const ray_t *ray, isect_ctx *ctx,
         if (!(v >= 0.0f && (u + v) <= 1.0f)) return;
         float t = dot3(e2, qvec) * inv;
         if (!(t >= ctx->t_min && t <= ctx->t_max)) return;
-        v3 p = V3(fma_(t, d.x, origin.x), fma_(t, d.y, origin.y), fma_(t, d.z, origin.z));
+        v3 p = V3(gfma_(t, d.x, origin.x), gfma_(t, d.y, origin.y), gfma_(t, d.z, origin.z));
         v3 v1 = add3(v0, e1), v2 = add3(v0, e2);
         v3 lo = V3(min_(v0.x, min_(v1.x, v2.x)) - hit_pad, min_(v0.y, min_(v1.y, v2.y)) - hit_pad,
                    min_(v0.z, min_(v1.z, v2.z)) - hit_pad);

@@ -52,7 +52,7 @@ def lib():
     global _lib
     if _lib is None:
         name = "liborc.so" if _cpu_has_fma() else "liborc_nofma.so"
-        path = os.path.join(_HERE, name)
+        path = os.environ.get("ORC_LIB") or os.path.join(_HERE, name)     # ORC_LIB: oracle/sensitivity.py's variants only
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

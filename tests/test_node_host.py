@@ -45,3 +45,15 @@ def test_webgpu_shaped_host_matches_oracle(tmp_path, orc):
     rgba = np.frombuffer((tmp_path / "fb.bin").read_bytes(), np.uint8).reshape(80, 80, 4)
     _, rgba_o, _ = orc.Scene.from_packed(cornell(80, 80)).render(3)
     assert np.array_equal(rgba, rgba_o)
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_async_napi_keeps_the_event_loop_free(tmp_path):
+    """traceAsync / syncAsync / readRgba8Async (napi_async_work, Promises): the event loop turns while a 64-spp trace
+    runs on a worker thread, blocking calls are refused meanwhile (ERR_CRT_BUSY), the image equals the synchronous
+    one, a destroyed handle rejects."""
+    out = subprocess.run([NODE, os.path.join(ROOT, "host", "async_demo.js"), "--size", "512", "--spp", "64"],
+                         capture_output=True, text=True, check=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["equal"] and info["busy"] and info["rejected"] and info["sample"] == 64
+    assert info["ticks"] > 10, info
