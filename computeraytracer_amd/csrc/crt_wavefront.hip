@@ -326,27 +326,30 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     }
 
     if (!FINISH) {
-    // 3. re-arm dead slots with the next (sample, pixel) work item.  The work range is split
-    //    into kWfShards contiguous sub-ranges with their own cursors; a wave looks at all cursors
-    //    with one wave-wide load, picks a non-empty shard (its own first) and takes what it
-    //    needs with ONE atomic.
+    // 3. re-arm dead slots with the next (sample, pixel) work item.  A queue's work range is split into kWfShards
+    //    contiguous sub-ranges with their own cursors, and several queues (batches) can be listed, oldest first.
+    //    Pass 0: the wave's OWN shard of every listed queue in turn, one atomic each -- the shards of a queue drain at
+    //    the same rate (every shard has the same number of waves), so at a batch boundary a wave simply goes on with
+    //    the next batch's queue instead of fighting for the last items of the old one (with small batches every
+    //    launch crosses a boundary: thousands of waves on the few cursors still open cost more than the launch).
+    //    Pass 1, only for lanes still empty: look at all cursors of a queue with one wave-wide load, take from a
+    //    non-empty shard, mark the queue done when there is none.
     {
         const bool want0 = in_pool && !alive;
         bool want = want0;
         const uint32_t lane = lane_id();
-        // several queues: the oldest batch's until it is dry, then the next one's, ... (published early)
-        uint32_t si = 0, sg = P.seg_order[0];
-        int tries = 0;
-        bool dry = __hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        for (int attempt = 0; attempt < 3 * (int)kWfRing; attempt++) {
-            if (dry) {
-                if (++si >= P.seg_n) break;
-                sg = P.seg_order[si]; tries = 0;
-                dry = __hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-                if (dry) continue;
-            }
+        uint32_t si = 0;
+        int pass = 0, tries = 0;
+        for (int attempt = 0; attempt < 6 * (int)kWfRing; attempt++) {
             const unsigned long long m = __ballot(want);
-            if (!m || tries >= 3) break;
+            if (!m) break;
+            if (si >= P.seg_n) {
+                if (pass == 1) break;
+                pass = 1; si = 0; tries = 0;
+                continue;
+            }
+            const uint32_t sg = P.seg_order[si];
+            if (__hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { si++; tries = 0; continue; }
             WfWorkQ *wq = P.wq + sg;
             const uint32_t wps = P.seg[sg].work_per_shard;
             const unsigned long long wtot = P.seg[sg].work_total;
@@ -355,21 +358,23 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             const unsigned long long hi = min(lo + (unsigned long long)wps, wtot);
             const uint32_t size_l = hi > lo ? (uint32_t)(hi - lo) : 0u;
             uint32_t s_pick = my_shard;
-            if (tries++ == 0) {
+            if (pass == 0) {
                 // one uniform load of the own cursor: skip the atomic when this shard is already dry
                 const unsigned long long lo0 = (unsigned long long)my_shard * wps;
                 const unsigned long long hi0 = min(lo0 + (unsigned long long)wps, wtot);
                 const uint32_t cur0 = __hip_atomic_load(&wq->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                si++;                                                // (one attempt per queue in this pass)
                 if (hi0 <= lo0 || cur0 >= (uint32_t)(hi0 - lo0)) continue;
             } else {
-                // own shard ran dry: look at every cursor at once (lane i loads shard i) and move on
+                // look at every cursor at once (lane i loads shard i) and take from a shard that still holds work
                 const uint32_t cur_l = __hip_atomic_load(&wq->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long avail = __ballot(cur_l < size_l);
                 if (!avail) {                                        // every shard is exhausted
                     if (lane == 0) __hip_atomic_store(&wq->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    dry = true;
+                    si++; tries = 0;
                     continue;
                 }
+                if (++tries > 2) { si++; tries = 0; }                // (at most two tries per queue; the slot retries next iteration)
                 const uint32_t rot = my_shard & 63u;
                 const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
                 s_pick = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
