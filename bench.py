@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--soup-tris", type=int, default=10_000_000)
     ap.add_argument("--band", type=int, default=8, help="rows per interleaved band for N>1 (0 = contiguous strips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="crt_set_option before the run (e.g. wf_pipes=1 for the single-pipe profile); noted in config")
     ap.add_argument("--cpu-crop", default="256x144", help="oracle sample: centre crop WxH at 1 spp")
     args = ap.parse_args()
 
@@ -110,6 +112,9 @@ def main():
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
     r.upload(ps)
+    for o in args.opt:
+        k, v = o.split("=")
+        r.set_option(k, int(v))
     sf = (HostStagedStripFrame if backend != "nccl" else StripFrame)(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
     sf.apply(r)
     t0 = time.time()
@@ -247,9 +252,10 @@ def main():
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
                        "partition": (f"rows dealt to {world} GPUs in bands of {args.band}" if world > 1 and args.band else f"{world} horizontal strip(s)")
                                     + ", scene replicated, all_gather of the rgba8 strips per step",
-                       "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s)" % t_build,
-                       "pipelining": "steps are software-pipelined like a display loop: frame() returns with the frame's longest "
-                                     "paths still in flight (they finish under the next frames); the gather after frame k ships the "
+                       "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s; crt_build_accel(LBVH) builds on the GPU in milliseconds)" % t_build,
+                       "options": args.opt,
+                       "pipelining": "steps are software-pipelined like a display loop: frame() returns with its batch in flight "
+                                     "(up to 32 batches, retired in order under the following frames); the gather after frame k ships the "
                                      "latest complete frame, the last frame is shipped after the final sync; every frame is complete "
                                      "and gathered inside the timed region"},
             "mpaths_per_s": round(paths / elapsed / 1e6, 3),

@@ -1,19 +1,18 @@
 """Time each tuning build (tune_*.so in the repo root, built with `make -C computeraytracer_amd/csrc
-OUT=$PWD/tune_x.so EXTRA=-DCRT_WF_...`) in the steady state: S2 1080p 64 spp, 12 pipelined calls + sync."""
+OUT=$PWD/tune_x.so EXTRA=-DCRT_WF_...`) in the steady state: S2 1080p, 12 pipelined 64-spp calls and 300 1-spp calls."""
 import glob, os, subprocess, sys
 code = r'''
 import sys, time; sys.path.insert(0,'.')
 from computeraytracer_amd import Renderer, scenes_synth
 ps = scenes_synth.atrium250k(1920,1080); r = Renderer(0); r.upload(ps).build_accel('bvh2')
 out = []
-for wpc in (16,):
-    r.set_option('wf_waves_per_cu', wpc)
+for spp, calls in ((64, 12), (1, 300)):
     best = 1e9
     for _ in range(2):
         r.reset(); r.sync(); t0 = time.perf_counter()
-        for _ in range(12): r.frame(64)
-        r.sync(); best = min(best, (time.perf_counter() - t0) * 1e3 / 12)
-    out.append('wpc %d: %.2f' % (wpc, best))
+        for _ in range(calls): r.frame(spp)
+        r.sync(); best = min(best, (time.perf_counter() - t0) * 1e3 / calls)
+    out.append('%d spp: %.3f ms' % (spp, best))
 print(' | '.join(out))
 '''
 libs = [None] + sorted(glob.glob('tune_*.so'))
