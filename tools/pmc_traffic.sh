@@ -6,7 +6,7 @@ mkdir -p $out
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/p$i -- python3 tools/prof_workload.py "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
+  echo "pass $i: $grp" >> $out/progress.txt; timeout -k 10 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/p$i -- python3 tools/prof_workload.py "$@" > $out/p$i.log 2>&1 || echo "pass $i failed" >> $out/progress.txt
 done
 python3 - <<PY
 import csv, glob, collections
