@@ -129,7 +129,11 @@ struct crt_ctx {
     DevBuf<uchar4> d_rgba;
     float4 *accum_bound = nullptr;
     uchar4 *rgba_bound = nullptr;
-    uint32_t sample = 0;
+    uint32_t sample = 0;            // samples requested so far (ComputeShader.wgsl:3 after that many frames)
+    uint32_t published = 0;         // ... of which this many have been turned into batches (or run by the single-kernel form)
+    uint32_t pending = 0;           // ... and this many wait to be merged with the next calls' (sample == published + pending)
+    bool in_publish = false;
+    int wf_cohort = 16;             // small calls are merged into batches of at least this many samples (1 = every call its own batch)
 
     DevBuf<unsigned long long> d_counters;
     bool counting = false;
@@ -227,7 +231,7 @@ int zero_state(crt_ctx *c)
         HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, n * sizeof(float4), c->stream));
         HIPCHK(c, hipMemsetAsync(rgba_ptr(c), 0, n * sizeof(uchar4), c->stream));
     }
-    c->sample = 0;
+    c->sample = 0; c->published = 0; c->pending = 0;
     return CRT_OK;
 }
 
@@ -1167,9 +1171,50 @@ int wf_check_dropped(crt_ctx *c)
     return CRT_OK;
 }
 
+int wf_trace_batch(crt_ctx *c, uint32_t n);
+
+// Samples per batch at most: the staging buffer stays below ~6 GB and work ids fit 32 bits.
+uint32_t wf_batch_cap(crt_ctx *c)
+{
+    const size_t npix = std::max<size_t>((size_t)c->tw * c->th, 1);
+    uint32_t cap = (uint32_t)std::max<size_t>(1, std::min<size_t>(256, (size_t)6e9 / (npix * 16)));
+    if (c->spp_per_launch) cap = std::min(cap, c->spp_per_launch);
+    return cap;
+}
+
+// Turn the samples requested by crt_trace into batches.  Small calls are merged (option "wf_cohort", 16 samples):
+// the shards of a batch's work queue are its samples, which sweep the frame together, so the paths in flight at any
+// time all start inside one band of the image, many samples deep -- and the rays of a launch touch a slice of the
+// scene instead of all of it (a batch of one sample per pixel has four whole frames in flight and
+// costs 1.5x as much per sample).  force: publish whatever is pending (crt_sync and every call that reads state).
+int wf_publish_pending(crt_ctx *c, bool force)
+{
+    if (c->in_publish) return CRT_OK;
+    const bool defer = c->wf_defer && !c->counting;
+    const uint32_t cap = wf_batch_cap(c);
+    c->in_publish = true;
+    int rc = CRT_OK;
+    while (c->pending > 0 && rc == CRT_OK) {
+        const uint32_t take = std::min(c->pending, cap);
+        if (take < cap && !force && defer && take < (uint32_t)c->wf_cohort) break;      // wait for more calls
+        c->pending -= take;
+        rc = wf_trace_batch(c, take);
+        if (rc != CRT_OK) {                                       // what could not be published never happened
+            c->sample -= take + c->pending;
+            c->pending = 0;
+        }
+    }
+    c->in_publish = false;
+    return rc;
+}
+
 // Finish whatever the pipeline still holds (no-op when nothing is in flight).
 int wf_flush(crt_ctx *c)
 {
+    if (c->pending && !c->in_publish && c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
+        int rc = wf_publish_pending(c, true);
+        if (rc) return rc;
+    }
     if (!c->run || !c->run->live) return CRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = wf_finish_all(c);
@@ -1191,7 +1236,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     if (!c->run) c->run = new WfRun();
     WfRun &r = *c->run;
     const WfConfig g = wf_config(c, n);
-    if (g.npix == 0 || n == 0) { int rc = wf_flush(c); c->sample += n; return rc; }
+    if (g.npix == 0 || n == 0) { int rc = wf_flush(c); c->published += n; return rc; }
     // counting folds counters on the host after every batch; otherwise batches are pipelined across calls
     const bool defer = c->wf_defer && !c->counting;
     const size_t staging_elems = (size_t)n * g.npix;
@@ -1217,7 +1262,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
         r.open.clear();
         WfBatch nb;
-        nb.n = n; nb.last_sample = c->sample + n; nb.id = 0;
+        nb.n = n; nb.last_sample = c->published + n; nb.id = 0;
         r.open.push_back(nb);
         r.seg_total[0] = g.work_total; r.seg_wps[0] = g.work_per_shard;
         for (uint32_t b = 0; b < kWfRing; b++) {
@@ -1254,7 +1299,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.band = c->band; W.stride = c->stride; W.phase = c->phase;
             W.tiles_x = g.tiles_x; W.tiles_y = g.tiles_y; W.npix_padded = g.npix_padded;
             W.list_cap = g.list_cap;
-            W.seg[0] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
+            W.seg[0] = WfSeg{g.work_total, g.work_per_shard, c->published + 1};
             W.seg_n = 1;
             W.n_samples = n;
             W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
@@ -1292,7 +1337,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         // The batches in flight keep their slots, queues and staging buffers; this one takes the next id and its
         // work flows into the slots that are free once the older queues are dry.
         WfBatch nb;
-        nb.n = n; nb.last_sample = c->sample + n; nb.id = (r.open.back().id + 1u) % r.ring;
+        nb.n = n; nb.last_sample = c->published + n; nb.id = (r.open.back().id + 1u) % r.ring;
         const uint32_t id = nb.id;
         r.seg_total[id] = g.work_total; r.seg_wps[id] = g.work_per_shard;
         r.queue_left[id] = r.work_left = true;
@@ -1300,7 +1345,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         for (int p = 0; p < r.K; p++) {
             WfPipe &pp = r.pipes[p];
             nb.from_it[p] = 0xFFFFFFFFu;                         // (set when the host sees the queue reset complete: wf_check_ready)
-            pp.W.seg[id] = WfSeg{g.work_total, g.work_per_shard, c->sample + 1};
+            pp.W.seg[id] = WfSeg{g.work_total, g.work_per_shard, c->published + 1};
             pp.W.n_samples = n;
             pp.W.batch_id = id; pp.W.keep_pool = 1;
             pp.tail_bound = 0; pp.blocks_now = r.trace_blocks;
@@ -1323,7 +1368,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
         nb.ready = false;                                        // listed by the launches enqueued once the host has seen that event complete
         r.open.push_back(nb);
     }
-    c->sample += n;
+    c->published += n;
     rc = wf_pump(c, false);
     if (rc == CRT_OK && !defer) rc = wf_flush(c);
     if (rc != CRT_OK && r.live) {
@@ -1576,25 +1621,18 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t left = n_samples;
     if (c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
-        // batch so that the staging buffer stays below ~6 GB and work ids fit 32 bits
-        const size_t npix = std::max<size_t>((size_t)c->tw * c->th, 1);
-        uint32_t cap = (uint32_t)std::max<size_t>(1, std::min<size_t>(256, (size_t)6e9 / (npix * 16)));
-        if (c->spp_per_launch) cap = std::min(cap, c->spp_per_launch);
-        while (left) {
-            uint32_t n = std::min(left, cap);
-            int rc = wf_trace_batch(c, n);
-            if (rc) return rc;
-            left -= n;
-        }
+        c->sample += n_samples; c->pending += n_samples;
+        int rc = wf_publish_pending(c, false);
+        if (rc) return rc;                                       // (what was not published is not part of the frame)
     } else {
         { int rc_ = wf_flush(c); if (rc_) return rc_; }
         uint32_t chunk = c->spp_per_launch ? c->spp_per_launch : 8u;
         while (left) {
             uint32_t n = std::min(left, chunk);
-            P.first_sample = c->sample + 1;                               // UpdateVariables.wgsl: sample++ first
+            P.first_sample = c->published + 1;                            // UpdateVariables.wgsl: sample++ first
             P.n_samples = n;
             HIPCHK(c, launch_trace(P, c->counting, c->accel_mode == CRT_ACCEL_NONE, c->stream));
-            c->sample += n;
+            c->published += n; c->sample += n;
             left -= n;
             c->last_launches++;
         }
@@ -1659,7 +1697,7 @@ int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(accum_ptr(c), in, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->sample = sample;
+    c->sample = sample; c->published = sample; c->pending = 0;
     return CRT_OK;
 }
 
@@ -1802,6 +1840,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_flush_ppw")) { c->wf_flush_ppw = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_ring")) { c->wf_ring = (int)std::min<int64_t>((int64_t)kWfRing, std::max<int64_t>(2, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_chunk")) { c->wf_chunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_cohort")) { c->wf_cohort = (int)std::min<int64_t>(256, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_ahead")) { c->wf_ahead = (int)std::min<int64_t>(32, std::max<int64_t>(2, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool_spp")) { c->wf_pool_spp = (int)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_feed_pct")) { c->wf_feed = (double)std::min<int64_t>(400, std::max<int64_t>(10, value)) / 100.0; return CRT_OK; }

@@ -115,11 +115,15 @@ int crt_reset(crt_ctx *ctx);
  * Asynchronous, and (option "wf_defer", default 1) PIPELINED across calls: a call publishes
  * its samples as a batch, enqueues the work the batch needs and returns without waiting for it;
  * up to "wf_ring" (default 32) batches are in flight, resolved in order under the following
- * crt_trace calls or in crt_sync.  A call only blocks for back-pressure (the ring is full).  So:
+ * crt_trace calls or in crt_sync.  A call only blocks for back-pressure (the ring is full).
+ * Small calls are MERGED: their samples become one batch once "wf_cohort" (default 16) samples
+ * have come together, or at crt_sync / any call that reads state (a batch of many samples per
+ * pixel keeps the paths in flight inside a band of the image and runs 1.4x faster per sample;
+ * the frames are the same bit for bit; "wf_cohort" = 1 makes every call its own batch).  So:
  *   - after crt_sync (or any crt_read_*, crt_counters, crt_last_*_ms) the buffers
  *     hold every sample requested so far;
  *   - in between, buffers bound with crt_bind_output hold, in stream order, the
- *     complete frame of an EARLIER crt_trace call -- at most wf_ring calls before the
+ *     complete frame of an EARLIER crt_trace call -- at most wf_ring batches before the
  *     last one -- never a half-resolved one.  A display/gather loop that shows the latest
  *     complete frame while the next ones render needs no sync at all. */
 int crt_trace(crt_ctx *ctx, uint32_t n_samples);
@@ -171,7 +175,7 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
  * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
  * (0 = auto: "wf_pool_spp" slots per tile pixel, 1 M..8 M); "wf_waves_per_cu": persistent traversal
  * waves per CU and pipe; "wf_pipes": sub-pools on separate streams (1..4); "wf_defer": 0 = every crt_trace
- * call runs its paths to the end; "wf_ring" (2..32 batches in flight), "wf_chunk" (iterations enqueued at
+ * call runs its paths to the end; "wf_ring" (2..32 batches in flight), "wf_cohort" (samples per batch that small calls are merged up to), "wf_chunk" (iterations enqueued at
  * a time), "wf_ahead" (iterations in flight per pipe before the call waits), "wf_feed_pct", "wf_finish_at",
  * "wf_flush_at", "wf_side_ppw", "wf_flush_ppw", "wf_tail_walk": pipeline tuning;
  * "quantize", "wf_width" (4 | 8: node width of the wavefront traversal; at crt_build_accel);

@@ -364,6 +364,7 @@ def test_batches_pipelined_across_calls(renderer, orc):
         stream = torch.cuda.Stream(device=dev)  # (the null stream's handle is 0, which means "the context's own")
         torch.cuda.synchronize()
         renderer.set_stream(stream.cuda_stream)
+        renderer.set_option("wf_cohort", 1)     # (every call its own batch: this is about the ring of batches)
         for ring in (2, 4):
             renderer.set_option("wf_ring", ring)
             acc_t.zero_(); rgba_t.zero_(); torch.cuda.synchronize()
@@ -383,7 +384,7 @@ def test_batches_pipelined_across_calls(renderer, orc):
         assert np.array_equal(bits(acc_t.cpu().numpy())[..., :3], bits(frames[8][0])[..., :3])
     finally:
         renderer.set_stream(None)
-        renderer.set_option("wf_defer", 1).set_option("wf_ring", 32)
+        renderer.set_option("wf_defer", 1).set_option("wf_ring", 32).set_option("wf_cohort", 16)
 
 
 def test_pipelined_calls_at_full_scale(renderer):
@@ -426,7 +427,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
                     "wf_chunk": int(rng.choice([1, 2, 4])), "wf_feed_pct": int(rng.choice([50, 100, 200])),
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
                     "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0])),
-                    "wf_ring": int(rng.choice([2, 3, 4, 32])), "wf_pool_spp": int(rng.choice([1, 2, 4])), "wf_ahead": int(rng.choice([2, 3, 6]))}
+                    "wf_ring": int(rng.choice([2, 3, 4, 32])), "wf_pool_spp": int(rng.choice([1, 2, 4])), "wf_ahead": int(rng.choice([2, 3, 6])),
+                    "wf_cohort": int(rng.choice([1, 1, 4, 16]))}
             for k, v in opts.items():
                 renderer.set_option(k, v)
             rect = None
@@ -454,7 +456,7 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             assert renderer.sample == total
     finally:
         for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 1, "wf_feed_pct": 100, "wf_finish_at": 32768, "wf_ahead": 3,
-                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 4}.items():
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 4, "wf_cohort": 16}.items():
             renderer.set_option(k, v)
 
 
@@ -678,8 +680,9 @@ def test_out_of_memory_is_reported_and_the_context_recovers(orc):
             r.upload(ps).build_accel("bvh2")
             r.set_option("debug_fail_alloc", k)
             with pytest.raises(CrtError) as e:
-                r.frame(2)
+                r.frame(2).sync()                    # (a small call may wait to be merged with the next ones: sync publishes it)
             assert e.value.code == -4, str(e.value)
+            assert r.sample == 0
             r.frame(2).sync()
             assert_same_image(r.read_accum(), r.read_rgba8(), acc_o, rgba_o)
         finally:
