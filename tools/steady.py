@@ -1,6 +1,5 @@
 """Steady-state cost per 64-spp call with batches pipelined across calls: S2 1080p, 24 calls + one sync, for the
-whole frame and for the row-band share of a 2-, 4- and 8-GPU run (one GPU rendering one share); sweeps of the
-chunk size (iterations per status readback), the park threshold and k_wf_finish's paths per wave."""
+whole frame and for the row-band share of a 2-, 4- and 8-GPU run (one GPU rendering one share)."""
 import sys, time
 sys.path.insert(0, '.')
 from computeraytracer_amd import Renderer, scenes_synth
@@ -17,7 +16,8 @@ def t(calls=24, n=2):
 for name, bands in (('frame', None), ('1/2 bands', (8, 2, 1)), ('1/4 bands', (8, 4, 1)), ('1/8 bands', (8, 8, 3))):
     if bands: r.set_row_bands(*bands)
     out = []
-    for chunk, feed, ppw in ((2, 100, 64), (4, 100, 64), (2, 80, 64), (2, 125, 64), (1, 100, 16)):
-        r.set_option('wf_chunk', chunk).set_option('wf_feed_pct', feed).set_option('wf_side_ppw', ppw)
-        out.append('c%d f%d w%d: %.2f' % (chunk, feed, ppw, t()))
+    for opts in ({}, {'wf_pool_spp': 8}, {'wf_pool_spp': 16}, {'wf_cohort': 128}, {'wf_ahead': 5}):
+        for k, v in opts.items(): r.set_option(k, v)
+        out.append('%s: %.2f' % (','.join('%s=%d' % kv for kv in opts.items()) or 'default', t()))
+        for k, v in {'wf_pool_spp': 4, 'wf_cohort': 16, 'wf_ahead': 3}.items(): r.set_option(k, v)
     print(name, ' | '.join(out), flush=True)
