@@ -490,8 +490,12 @@ int upload_geometry(crt_ctx *c, int mode)
 //             and k_wf_resolve adds the batch to the accumulator -- on the context's stream, under the pool's work.
 //   flush     crt_sync and every call that reads or changes state: run everything to its end.
 //
-// After every chunk of iterations k_wf_status reduces what the driver needs (queue cursors, rays listed, paths alive
-// per batch) to one small record that is copied back asynchronously.
+//   cohorts   small calls are merged: crt_trace only notes their samples, which become one batch once wf_cohort of
+//             them have come together (wf_publish_pending) -- a batch of many samples per pixel keeps the paths in
+//             flight inside a band of the image.
+//
+// What the driver needs to know about an iteration (queue cursors, rays listed, paths alive per batch) is written
+// into a pinned host record by the first wave of the NEXT iteration's shade launch (write_status) and polled here.
 constexpr int kStatusRing = crt_ctx::kStatusSlots;
 
 int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uint32_t ring)
@@ -540,7 +544,7 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uin
                 HIPCHK(c, hipMemset(c->w_ctl[p].p, 0, sizeof(WfCtl)));
             }
             if (!c->h_status[p]) {
-                // coherent pinned host memory that k_wf_status writes directly (no copy kernel behind every chunk)
+                // coherent pinned host memory that the shade kernel's first wave writes directly (write_status)
                 HIPCHK(c, hipHostMalloc((void **)&c->h_status[p], kStatusRing * sizeof(WfStatus), hipHostMallocMapped | hipHostMallocCoherent));
                 std::memset(c->h_status[p], 0, kStatusRing * sizeof(WfStatus));
                 HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_status[p], c->h_status[p], 0));
@@ -1270,7 +1274,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             for (int p = 0; p < crt_ctx::kMaxPipes; p++) r.listed_until[b][p] = 0;
         }
         r.queue_left[0] = r.work_left = true;
-        r.consumed_total = 0; r.rate_consumed = 0; r.rate_its = 0;
+        r.consumed_total = 0; r.rate_consumed = 0; r.rate_its = 0;                // (rate_its: set below, once the pipes' iteration numbers are)
         r.per_it = (double)g.Pp;                                 // an empty pool takes a slot's worth per slot
         r.all_evicting = false; r.poll_next = 0;
         for (int p = 0; p < r.K; p++) {
@@ -1320,6 +1324,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             r.pipes[p].stream = c->pipe_stream[p];
             r.pipes[p].blocks_now = r.trace_blocks;
         }
+        for (int p = 0; p < r.K; p++) r.rate_its += r.pipes[p].it_confirmed;
         // The context's stream sets the pool up and forks the pipes (and, later, finishes stragglers and
         // resolves).  The pipes run on their own streams.
         HIPCHK(c, wf_launch_init(r.pipes[0].W, c->stream));
