@@ -147,8 +147,8 @@ struct crt_ctx {
     uint32_t wf_pool = 0;           // 0 = auto
     uint32_t wf_waves_per_cu = 16;  // per pipe
     int num_cu = 0;
-    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing];
-    DevBuf<uint4> w_rng, w_misc;
+    DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing], w_recA, w_recB;
+    DevBuf<uint4> w_rng, w_misc, w_recC;
     DevBuf<float2> w_hit;
     DevBuf<uint32_t> w_vis, w_list_ext, w_tea;
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
@@ -501,6 +501,9 @@ constexpr int kStatusRing = crt_ctx::kStatusSlots;
 int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uint32_t ring)
 {
     if (c->w_list_ext.n < list_elems) HIPCHK(c, c->w_list_ext.alloc(list_elems));
+    if (c->w_recA.n < list_elems) HIPCHK(c, c->w_recA.alloc(list_elems));      // the ray records, one per list entry
+    if (c->w_recB.n < list_elems) HIPCHK(c, c->w_recB.alloc(list_elems));
+    if (c->w_recC.n < list_elems) HIPCHK(c, c->w_recC.alloc(list_elems));
     // (each array on its own: after a failed allocation that array reports n == 0 and is retried by the next call)
     if (c->w_ray_o.n < P) HIPCHK(c, c->w_ray_o.alloc(P));
     if (c->w_ray_d.n < P) HIPCHK(c, c->w_ray_d.alloc(P));
@@ -1290,6 +1293,8 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             for (int b = 0; b < 2; b++)
                 for (int k = 0; k < 4; k++)
                     W.list[b][k] = c->w_list_ext.p + g.list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * g.list_cap * kWfShards;
+            W.recA = c->w_recA.p + g.list_per_pipe * (size_t)p; W.recB = c->w_recB.p + g.list_per_pipe * (size_t)p;
+            W.recC = c->w_recC.p + g.list_per_pipe * (size_t)p;
             for (uint32_t b = 0; b < kWfRing; b++) {
                 W.staging[b] = c->w_staging[b < r.ring ? b : 0].p;
                 W.side_base[b] = (b * (uint32_t)crt_ctx::kMaxPipes + (uint32_t)p) * kWfSideCap;
@@ -1433,7 +1438,7 @@ void crt_destroy(crt_ctx *c)
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
-    c->w_vis.release(); c->w_list_ext.release(); c->w_tea.release(); c->w_wq.release();
+    c->w_vis.release(); c->w_list_ext.release(); c->w_recA.release(); c->w_recB.release(); c->w_recC.release(); c->w_tea.release(); c->w_wq.release();
     if (c->pub_stream) (void)hipStreamSynchronize(c->pub_stream);
     for (int f = 0; f < crt_ctx::kFinishStreams; f++) {
         if (c->fin_stream[f]) { (void)hipStreamSynchronize(c->fin_stream[f]); (void)hipStreamDestroy(c->fin_stream[f]); }

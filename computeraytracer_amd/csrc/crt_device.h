@@ -156,6 +156,12 @@ struct WfParams {
     float2 *hit;
     uint32_t *vis;
     uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
+    // The rays themselves as compacted records, one per list entry at [(parity*4 + class) * list_cap*kWfShards + shard*list_cap + i]:
+    //   recA (o.xyz, exclude bits)   recB extension ray: (d.xyz, slot | kWfListAlsoExt if already resolved)
+    //                                     shadow ray:    (light dir.xyz, t of the light's own primitive)
+    //   recC shadow rays only: (slot, light primitive index, its slot, -)
+    float4 *recA, *recB;
+    uint4 *recC;
     float4 *staging[kWfRing];        // finished samples, per batch id (several batches can be in flight)
     uint32_t batch_id;           // id of the newest batch (k_wf_init: the batch being set up; k_wf_resolve / k_wf_finish: the batch to resolve / finish)
     WfStatus *status_out;            // k_wf_shade: where its first wave writes the PREVIOUS iteration's status record (pinned host memory), or null

@@ -57,15 +57,14 @@ __device__ __forceinline__ bool beats(float t, float t_min, float t_max, uint32_
     return (t >= t_min) && (t < t_max || (t == t_max && (b_slot == kNoHit || index > b_index)));
 }
 
-// One primitive against one ray (ComputeShader.wgsl:520-632 + category 2).
+// One primitive against one ray (ComputeShader.wgsl:520-632 + category 2), the primitive given as its record
+// (A, B, C of `prim`, D of `primD` -- D is looked at for patches only).
 // Updates (t_max, b_index, b_slot) when the primitive becomes the best hit.
 template <bool LITERAL>
-__device__ __forceinline__ bool hit_test(const DevScene &S, uint32_t slot, f3 o, f3 d, uint32_t exclude,
-                                         float t_min, float &t_max, uint32_t &b_index, uint32_t &b_slot)
+__device__ __forceinline__ bool hit_test_rec(const float4 A, const float4 B, const float4 C, const float4 D, float hit_pad,
+                                             uint32_t slot, f3 o, f3 d, uint32_t exclude, float t_min, float &t_max,
+                                             uint32_t &b_index, uint32_t &b_slot)
 {
-    const float4 A = S.prim[3 * slot + 0];
-    const float4 B = S.prim[3 * slot + 1];
-    const float4 C = S.prim[3 * slot + 2];
     const uint32_t index = f_bits(B.w);
     if (exclude == index) return false;                       // :527-532
     const uint32_t cat = f_bits(A.w) & 3u;
@@ -88,14 +87,13 @@ __device__ __forceinline__ bool hit_test(const DevScene &S, uint32_t slot, f3 o,
         else if (!beats<false>(t, t_min, t_max, index, b_index, b_slot)) return false;
         f3 p = ray_at(o, d, t);
         f3 v1 = v0 + e1, v2 = v0 + e2;
-        float pad = S.hit_pad;
+        float pad = hit_pad;
         bool in = p.x >= min_(v0.x, min_(v1.x, v2.x)) - pad && p.x <= max_(v0.x, max_(v1.x, v2.x)) + pad &&
                   p.y >= min_(v0.y, min_(v1.y, v2.y)) - pad && p.y <= max_(v0.y, max_(v1.y, v2.y)) + pad &&
                   p.z >= min_(v0.z, min_(v1.z, v2.z)) - pad && p.z <= max_(v0.z, max_(v1.z, v2.z)) + pad;
         if (!in) return false;
     } else if (cat == 0u) {
         // planar patch :525-583 (unit normal and e.e precomputed with the same ops)
-        const float4 D = S.primD[slot];
         f3 n = xyz(D);
         float ndotd = dot(n, d);
         if (ndotd > 0.0f) { n = -n; ndotd = -ndotd; }          // :541-545 (dot(-n,d) == -dot(n,d) exactly)
@@ -131,11 +129,23 @@ __device__ __forceinline__ bool hit_test(const DevScene &S, uint32_t slot, f3 o,
     return true;
 }
 
-// Hit attributes for the winning primitive (position, shading normal).
-__device__ __forceinline__ void hit_attributes(const DevScene &S, uint32_t slot, f3 o, f3 d, float t,
-                                               f3 &pos, f3 &nrm, uint32_t &meta)
+// The same with the record fetched from the scene (primD only for a patch that is not excluded).
+template <bool LITERAL>
+__device__ __forceinline__ bool hit_test(const DevScene &S, uint32_t slot, f3 o, f3 d, uint32_t exclude,
+                                         float t_min, float &t_max, uint32_t &b_index, uint32_t &b_slot)
 {
     const float4 A = S.prim[3 * slot + 0];
+    const float4 B = S.prim[3 * slot + 1];
+    const float4 C = S.prim[3 * slot + 2];
+    float4 D = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (exclude != f_bits(B.w) && (f_bits(A.w) & 3u) == 0u) D = S.primD[slot];
+    return hit_test_rec<LITERAL>(A, B, C, D, S.hit_pad, slot, o, d, exclude, t_min, t_max, b_index, b_slot);
+}
+
+// Hit attributes for the winning primitive (position, shading normal), from its record.
+__device__ __forceinline__ void hit_attributes_rec(const float4 A, const float4 B, const float4 C, const float4 D, f3 o, f3 d,
+                                                   float t, f3 &pos, f3 &nrm, uint32_t &meta)
+{
     meta = f_bits(A.w);
     const uint32_t cat = meta & 3u;
     pos = ray_at(o, d, t);
@@ -143,10 +153,21 @@ __device__ __forceinline__ void hit_attributes(const DevScene &S, uint32_t slot,
         nrm = normalize(pos - xyz(A));                         // :618 (always outward)
     } else {
         f3 n;
-        if (cat == 0u) n = xyz(S.primD[slot]);
-        else n = normalize(cross(xyz(S.prim[3 * slot + 1]), xyz(S.prim[3 * slot + 2])));
+        if (cat == 0u) n = xyz(D);
+        else n = normalize(cross(xyz(B), xyz(C)));
         nrm = (dot(n, d) > 0.0f) ? -n : n;                     // :541-544
     }
+}
+
+__device__ __forceinline__ void hit_attributes(const DevScene &S, uint32_t slot, f3 o, f3 d, float t,
+                                               f3 &pos, f3 &nrm, uint32_t &meta)
+{
+    const float4 A = S.prim[3 * slot + 0];
+    const uint32_t cat = f_bits(A.w) & 3u;
+    float4 B = float4{0.0f, 0.0f, 0.0f, 0.0f}, C = B, D = B;
+    if (cat == 0u) D = S.primD[slot];
+    else if (cat == 2u) { B = S.prim[3 * slot + 1]; C = S.prim[3 * slot + 2]; }
+    hit_attributes_rec(A, B, C, D, o, d, t, pos, nrm, meta);
 }
 
 // ---------------------------------------------------------------- traversal
@@ -315,6 +336,18 @@ __device__ __forceinline__ float power_heuristic(float nf, float f_pdf, float ng
 {
     float f = nf * f_pdf, g = ng * g_pdf;                      // :297-302
     return (f * f) / (f * f + g * g);
+}
+
+// :357-377 with the light's 1/area given.
+__device__ __forceinline__ float compute_light_pdf_area(float light_area_pdf, float inv_nlight, f3 position,
+                                                        f3 normal, f3 ray_origin, f3 ray_direction)
+{
+    float abs_cos_theta = max_(0.00001f, abs_(dot(normal, -ray_direction)));
+    float distance = length(position - ray_origin);
+    float distance_squared = pow_(distance, 2.0f);             // :368
+    float geometric_term = abs_cos_theta / distance_squared;
+    float light_solid_angle_pdf = light_area_pdf / geometric_term;
+    return inv_nlight * light_solid_angle_pdf;
 }
 
 // :357-377.  `emission_index` indexes lights[] (sic, Q7), clamped.

@@ -100,23 +100,128 @@ __device__ __forceinline__ void wavelengths_of(uint32_t lambda, uint32_t wl[4])
     wl[3] = (lambda + 12u) % kNLambda;                           // :321
 }
 
+// A light as the NEE step needs it: its record (data1/2/3 + emission index, primitive index, 1/area) and the record of
+// its own primitive.  UNIFORM (scenes with ONE light -- the reference's cornell box and everything built around it): every
+// address is the same for all lanes, so the loads are scalar loads from the constant address space (the scene is read-only
+// during a trace), issued at the top of the kernel under the slot streams' round trip -- instead of a chain of four
+// dependent per-lane fetches (light -> slot of its primitive -> the primitive's record -> 1/area for the pdf) in the
+// middle of the shade step, where a wave squeezed in beside the traversal kernel's waves has nothing to hide them behind.
+struct LightRec { float4 L0, L1, L2, A, B, C, D; uint32_t slot; float pdf_area; };
+
+template <bool UNIFORM>
+__device__ __forceinline__ LightRec load_light(const DevScene &S, uint32_t li)
+{
+    LightRec r;
+    r.A = float4{0.0f, 0.0f, 0.0f, 0.0f}; r.B = r.A; r.C = r.A; r.D = r.A; r.slot = kNoHit; r.pdf_area = 0.0f;
+    if (UNIFORM) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) v4f *cptr4;
+        typedef const __attribute__((address_space(4))) uint32_t *cptr1;
+        auto ld = [](cptr4 p) { const v4f v = *p; return float4{v.x, v.y, v.z, v.w}; };
+        const cptr4 lg = (cptr4)S.lights;
+        r.L0 = ld(lg); r.L1 = ld(lg + 1); r.L2 = ld(lg + 2);
+        const uint32_t include = f_bits(r.L1.w);
+        if (include < S.nprim) {
+            r.slot = ((cptr1)S.slot_of_index)[include];
+            const cptr4 pg = (cptr4)S.prim + 3 * (size_t)r.slot;
+            r.A = ld(pg); r.B = ld(pg + 1); r.C = ld(pg + 2); r.D = ld((cptr4)S.primD + r.slot);
+            // the light's 1/area as compute_light_pdf() finds it: lights[min(emission index of the primitive, nlight-1)] = lights[0]
+            r.pdf_area = r.L2.w;
+        }
+    } else {
+        r.L0 = S.lights[3 * li + 0]; r.L1 = S.lights[3 * li + 1]; r.L2 = S.lights[3 * li + 2];
+        const uint32_t include = f_bits(r.L1.w);
+        if (include < S.nprim) {
+            r.slot = S.slot_of_index[include];
+            r.A = S.prim[3 * (size_t)r.slot + 0]; r.B = S.prim[3 * (size_t)r.slot + 1]; r.C = S.prim[3 * (size_t)r.slot + 2];
+            r.D = S.primD[r.slot];
+            uint32_t l2 = (f_bits(r.A.w) >> 4) & 0x3FFFu;              // compute_light_pdf(): lights[emission index] (sic, Q7), clamped
+            if (l2 >= S.nlight) l2 = S.nlight - 1u;
+            r.pdf_area = S.lights[3 * l2 + 2].w;
+        }
+    }
+    return r;
+}
+
 // compute_light_radiance's tail (:388-400) for a light primitive hit at t_l along the shadow ray: the NEE term before
 // the caller's BRDF * beta (:187).
-__device__ __forceinline__ f4 nee_term(const DevScene &S, uint32_t l_slot, f3 pos, f3 ldir, float t_l, float cos_theta,
-                                       uint32_t light_emission, const uint32_t wl[4])
+__device__ __forceinline__ f4 nee_term(const DevScene &S, const LightRec &L, f3 pos, f3 ldir, float t_l, float cos_theta,
+                                       const f4 spec)
 {
     f3 lp, ln; uint32_t lmeta;
-    hit_attributes(S, l_slot, pos, ldir, t_l, lp, ln, lmeta);
-    f4 spec = sample_spectrum(S, light_emission, wl);
+    hit_attributes_rec(L.A, L.B, L.C, L.D, pos, ldir, t_l, lp, ln, lmeta);
     f4 le = spec * cos_theta;
-    float pdf_l = compute_light_pdf(S, (lmeta >> 4) & 0x3FFFu, lp, ln, pos, ldir);
+    float pdf_l = compute_light_pdf_area(L.pdf_area, S.inv_nlight, lp, ln, pos, ldir);
     float pdf_b = cos_theta / CRT_PI;
     float weight_l = power_heuristic(1.0f, pdf_l, 1.0f, pdf_b);
     return (le * weight_l) / pdf_l;
 }
 
-struct ShadeOut { bool alive, emit_ext, ext_primary, emit_sh, sh_primary; uint32_t batch; };
 struct ShadeCnt { uint32_t rays = 0, bounces = 0, shadow = 0, hits = 0, paths = 0, prims = 0, walk = 0; };
+struct ShadowOut { bool emit; f3 d; float t_l; uint32_t l_index, l_slot; };
+
+// compute_light_radiance (:379-408) from the sampled point on the light to the visibility test: intersects the light's own
+// primitive (shadow_intersect's "closest hit == the light", :697-705, starts there), and either adds what can be decided
+// without a walk to `radiance` or stores the NEE term and describes the shadow ray to trace.
+template <bool COUNT, bool FINISH>
+__device__ __forceinline__ ShadowOut light_sample(const WfParams &P, const LightRec &L, uint32_t slot, f3 pos, f3 nrm, uint32_t b_index,
+                                                  float u, float v2, f4 brdf, f4 beta, f4 &radiance, const uint32_t wl[4], ShadeCnt &cn)
+{
+    const DevScene &S = P.sc;
+    ShadowOut out{false, f3{0.0f, 0.0f, 0.0f}, 0.0f, 0u, 0u};
+    f3 pl = (xyz(L.L0) + xyz(L.L1) * u) + xyz(L.L2) * v2;
+    f3 ldir = normalize(pl - pos);
+    const uint32_t include = f_bits(L.L1.w);
+    if (COUNT) { cn.rays++; cn.shadow++; }
+    // shadow_intersect (:697-705): the light's own primitive first
+    float t_l = CRT_INFINITY;
+    uint32_t l_index = kNoHit, l_slot = kNoHit;
+    const bool sh_finite = finite3(ldir) && finite3(pos);
+    if (include < S.nprim && sh_finite) {
+        hit_test_rec<false>(L.A, L.B, L.C, L.D, S.hit_pad, L.slot, pos, ldir, b_index, 0.001f, t_l, l_index, l_slot);
+        if (COUNT) cn.prims++;
+    }
+    // cos_theta == 0 (the light sample is behind the surface): le = spec*0 is exactly 0, so the
+    // NEE term (:400) is exactly +0 whatever the visibility -- adding it changes nothing, and
+    // the shadow ray need not be walked (weight and pdf are finite: abs_cos >= 1e-5, :366).
+    const float cos_theta = max_(0.0f, dot(nrm, ldir));
+    if (!sh_finite) {
+        // A non-finite shadow ray (the light sample coincides with the hit point, or a light record
+        // with non-finite coordinates): normalize() has put a NaN into its direction, and under the
+        // reference's reject-form tests (:546,:557,:566,:605,:609) a NaN passes every test of every
+        // patch and sphere (never this project's triangles), so "the closest hit" of shadow_intersect
+        // is simply the LAST patch / sphere of the array that is not excluded -- the loop's result in
+        // closed form (S.nf_last, found at upload).  If that is the light (:700) the NEE term is added:
+        // le = spec * max(0, NaN) = 0 and pdf_l = NaN make it NaN in every wavelength (:393-400).
+        const uint32_t w = S.nf_last[0] != b_index ? S.nf_last[0] : S.nf_last[1];
+        if (COUNT) cn.prims += S.nprim;
+        if (w != kNoHit && w == include) {
+            if (COUNT) cn.hits++;
+            const float qn = bits_f(0x7FC00000u);
+            radiance = radiance + f4{qn, qn, qn, qn};
+        }
+    } else if (l_slot != kNoHit && cos_theta > 0.0f) {
+        if (COUNT) cn.hits++;
+        const f4 nee = nee_term(S, L, pos, ldir, t_l, cos_theta, sample_spectrum(S, f_bits(L.L0.w), wl));
+        f4 c = (brdf * nee) * beta;          // added to radiance iff the light is visible
+        P.nee[slot] = float4{c.x, c.y, c.z, c.w};
+        if (FINISH) {                        // (k_wf_finish traces from the slot arrays; the pool's
+            P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};   //  traversal kernel from the ray records)
+            P.vis[slot] = include;
+        }
+        out = ShadowOut{true, ldir, t_l, include, l_slot};
+        if (COUNT) cn.walk++;
+    }
+    return out;
+}
+
+// (o, excl, d, resolved: the extension ray; sd, t_l, l_index, l_slot: the shadow ray -- what k_wf_shade copies into the
+// compacted ray records the traversal kernel streams; a shadow ray starts where the extension ray does)
+struct ShadeOut {
+    bool alive, emit_ext, ext_primary, emit_sh, sh_primary; uint32_t batch;
+    f3 o; uint32_t excl; f3 d; uint32_t resolved;
+    f3 sd; float t_l; uint32_t l_index, l_slot;
+};
 
 // One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
 // driven by k_wf_finish (no re-arming from the work queue; the caller traces the emitted rays itself).
@@ -126,6 +231,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     const DevScene &S = P.sc;
     PathRegs R;
     R.flags = 0;
+    LightRec LU{};
+    if (S.nlight == 1u) LU = load_light<true>(S, 0u);
     // Every per-slot stream is loaded up front in ONE batch (the kernel is bound by dependent
     // memory round trips, not by bytes: a dead slot's extra 140 B cost nothing next to that).
     uint4 misc = uint4{0, 0, 0, 0}, rs = uint4{0, 0, 0, 0};
@@ -141,6 +248,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     bool emit_ext = false, emit_sh = false;
     bool ext_primary = false, sh_primary = false;     // ray classes: camera ray / shadow ray of a camera-ray hit
     bool finished = false;
+    f3 out_sd = f3{0, 0, 0}; float out_tl = 0.0f; uint32_t out_lindex = 0, out_lslot = 0;   // the shadow ray, if one is emitted
     // the hit primitive's whole record, also in one batch (valid only for an alive slot with a hit)
     const uint32_t h_slot = f_bits(h.y);
     const bool has_hit = alive && !(R.flags & kWfDying) && h_slot != kNoHit;
@@ -216,49 +324,15 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                         if (li >= S.nlight) li = S.nlight - 1u;
                         float u = rnd(R.rng);
                         float v2 = rnd(R.rng);
-                        const float4 L0 = S.lights[3 * li + 0], L1 = S.lights[3 * li + 1], L2 = S.lights[3 * li + 2];
-                        f3 pl = (xyz(L0) + xyz(L1) * u) + xyz(L2) * v2;
-                        f3 ldir = normalize(pl - pos);
-                        const uint32_t include = f_bits(L1.w);
-                        if (COUNT) { cn.rays++; cn.shadow++; }
-                        // shadow_intersect (:697-705): the light's own primitive first
-                        float t_l = CRT_INFINITY;
-                        uint32_t l_index = kNoHit, l_slot = kNoHit;
-                        const bool sh_finite = finite3(ldir) && finite3(pos);
-                        if (include < S.nprim && sh_finite) {
-                            hit_test<false>(S, S.slot_of_index[include], pos, ldir, b_index, 0.001f, t_l, l_index, l_slot);
-                            if (COUNT) cn.prims++;
-                        }
-                        // cos_theta == 0 (the light sample is behind the surface): le = spec*0 is exactly 0, so the
-                        // NEE term (:400) is exactly +0 whatever the visibility -- adding it changes nothing, and
-                        // the shadow ray need not be walked (weight and pdf are finite: abs_cos >= 1e-5, :366).
-                        const float cos_theta = max_(0.0f, dot(nrm, ldir));
-                        if (!sh_finite) {
-                            // A non-finite shadow ray (the light sample coincides with the hit point, or a light record
-                            // with non-finite coordinates): normalize() has put a NaN into its direction, and under the
-                            // reference's reject-form tests (:546,:557,:566,:605,:609) a NaN passes every test of every
-                            // patch and sphere (never this project's triangles), so "the closest hit" of shadow_intersect
-                            // is simply the LAST patch / sphere of the array that is not excluded -- the loop's result in
-                            // closed form (S.nf_last, found at upload).  If that is the light (:700) the NEE term is added:
-                            // le = spec * max(0, NaN) = 0 and pdf_l = NaN make it NaN in every wavelength (:393-400).
-                            const uint32_t w = S.nf_last[0] != b_index ? S.nf_last[0] : S.nf_last[1];
-                            if (COUNT) cn.prims += S.nprim;
-                            if (w != kNoHit && w == include) {
-                                if (COUNT) cn.hits++;
-                                const float qn = bits_f(0x7FC00000u);
-                                R.radiance = R.radiance + f4{qn, qn, qn, qn};
-                            }
-                        } else if (l_slot != kNoHit && cos_theta > 0.0f) {
-                            if (COUNT) cn.hits++;
-                            const f4 nee = nee_term(S, l_slot, pos, ldir, t_l, cos_theta, f_bits(L0.w), wl);
-                            f4 c = (brdf * nee) * R.beta;          // added to radiance iff the light is visible
-                            P.nee[slot] = float4{c.x, c.y, c.z, c.w};
-                            P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};
-                            P.vis[slot] = include;
+                        // (one light: its records were fetched with scalar loads at the top; else per lane, here)
+                        ShadowOut sh;
+                        if (S.nlight == 1u) sh = light_sample<COUNT, FINISH>(P, LU, slot, pos, nrm, b_index, u, v2, brdf, R.beta, R.radiance, wl, cn);
+                        else sh = light_sample<COUNT, FINISH>(P, load_light<false>(S, li), slot, pos, nrm, b_index, u, v2, brdf, R.beta, R.radiance, wl, cn);
+                        if (sh.emit) {
                             emit_sh = true;
                             sh_primary = depth == 0u;
                             R.flags |= kWfShadow;
-                            if (COUNT) cn.walk++;
+                            out_sd = sh.d; out_tl = sh.t_l; out_lindex = sh.l_index; out_lslot = sh.l_slot;
                         }
                         f3 new_direction = cosine_hemisphere(R.rng, nrm, R.last_pdf);
                         float cos_theta2 = abs_(dot(nrm, new_direction));
@@ -427,13 +501,13 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     }
 
     // 4. write the slot back
+    uint32_t resolved = 0u;
     if (in_pool) {
         if (alive) {
             P.ray_o[slot] = float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)};
             // A non-finite ray (e.g. refract at the numerical edge of total reflection) is decided
             // by the reference loop in its own order; do that here and flag the ray as resolved
             // so the traversal kernel stays free of the fallback.
-            uint32_t resolved = 0u;
             if (emit_ext && (!finite3(R.ray_o) || !finite3(R.ray_d))) {
                 P.hit[slot] = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, R.ray_o.x, R.ray_o.y, R.ray_o.z,
                                                 R.ray_d.x, R.ray_d.y, R.ray_d.z, R.exclude);
@@ -447,7 +521,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
         P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
     }
-    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, (R.flags >> kWfBatchShift) & (kWfRing - 1u)};
+    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, (R.flags >> kWfBatchShift) & (kWfRing - 1u),
+                    R.ray_o, R.exclude, R.ray_d, resolved, out_sd, out_tl, out_lindex, out_lslot};
 }
 
 // What the host's driver needs to know about iteration it_end - 1 of this pipe (lane i looks at shard i of
@@ -501,7 +576,6 @@ __device__ __noinline__ void write_status(const WfCtl *ctl, const WfWorkQ *wq, u
 template <bool COUNT>
 __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_wf_shade(const WfParams P, uint32_t it)
 {
-    const DevScene &S = P.sc;
     const uint32_t ring = it & 3u, lbuf = it & 1u;
     WfCtl *ctl = P.ctl;
     static_assert(kWfShards == 64, "one lane per shard");
@@ -595,11 +669,27 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         }
         b0 = __shfl(b0, 0, 64); b1 = __shfl(b1, 0, 64); b2 = __shfl(b2, 0, 64); b3 = __shfl(b3, 0, 64);
         const size_t region = (size_t)my_shard * P.list_cap;
-        if (cl0) P.list[lbuf][0][region + b0 + prefix_popc(m0, lane)] = slot;
-        if (cl1) P.list[lbuf][1][region + b1 + prefix_popc(m1, lane)] = slot;
-        const uint32_t sh_entry = slot | (emit_ext ? kWfListAlsoExt : 0u);
-        if (cl2) P.list[lbuf][2][region + b2 + prefix_popc(m2, lane)] = sh_entry;
-        if (cl3) P.list[lbuf][3][region + b3 + prefix_popc(m3, lane)] = sh_entry;
+        // Next to every list entry goes the ray itself, as a compacted record at the same position: the traversal
+        // kernel streams rays in list order -- one coalesced round trip per refill instead of list entry -> slot ->
+        // ray_o / ray_d (-> light index -> its slot), three to four dependent ones through HBM-resident pool arrays.
+        const size_t cls_stride = (size_t)P.list_cap * kWfShards;
+        if (emit_ext) {
+            const uint32_t c = cl0 ? 0u : 1u;
+            const size_t e = region + (cl0 ? b0 + prefix_popc(m0, lane) : b1 + prefix_popc(m1, lane));
+            P.list[lbuf][c][e] = slot;
+            const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + e;
+            P.recA[g] = float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)};
+            P.recB[g] = float4{so.d.x, so.d.y, so.d.z, bits_f(slot | (so.resolved ? kWfListAlsoExt : 0u))};
+        }
+        if (emit_sh) {
+            const uint32_t c = cl2 ? 2u : 3u;
+            const size_t e = region + (cl2 ? b2 + prefix_popc(m2, lane) : b3 + prefix_popc(m3, lane));
+            P.list[lbuf][c][e] = slot | (emit_ext ? kWfListAlsoExt : 0u);
+            const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + e;
+            P.recA[g] = float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)};
+            P.recB[g] = float4{so.sd.x, so.sd.y, so.sd.z, so.t_l};
+            P.recC[g] = uint4{slot, so.l_index, so.l_slot, 0u};
+        }
     }
     if (COUNT) {
         wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
@@ -643,6 +733,17 @@ __device__ __forceinline__ void tri_test(const float4 A, const float4 B, const f
     }
 }
 
+// Pop entry sp of a lane's stack: the LDS part with a DS read, unconditionally (index clamped), and the global overflow
+// area under a branch of its own.  (Written as one conditional expression the two became a FLAT load of a selected
+// address: every pop went through the texture-address path -- the unit this kernel saturates -- at global-memory
+// latency, with a wait for all outstanding loads behind it.)
+__device__ __forceinline__ int stack_pop(const int *stk, const int *ovf, size_t ovl, int sp)
+{
+    int v = stk[(sp < kWfStack ? sp : kWfStack - 1) * 64];
+    if (sp >= kWfStack) v = *(const volatile int *)(ovf + (size_t)(sp - kWfStack) * ovl);   // (volatile: keeps it apart from the DS read)
+    return v;
+}
+
 // Persistent waves.  A wave owns a chunk of one shard's ray list at a time; entry i of a shard:
 // entries of the four class lists in order (camera rays, bounce rays, shadow rays of camera hits, shadow rays).
 // Traversal is "while-while": a bounded run of inner-node steps (lanes that reach a leaf wait,
@@ -660,16 +761,13 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     const f3 qscale = f3{P.sc.qscale[0], P.sc.qscale[1], P.sc.qscale[2]}, qbase = f3{P.sc.qbase[0], P.sc.qbase[1], P.sc.qbase[2]};
     const float4 *__restrict__ prim = P.sc.prim;
     const float4 *__restrict__ primD = P.sc.primD;
-    const uint32_t *__restrict__ slot_of_index = P.sc.slot_of_index;
-    const float4 *__restrict__ g_ray_o = P.ray_o;
-    const float4 *__restrict__ g_ray_d = P.ray_d;
-    const float4 *__restrict__ g_sh_d = P.sh_d;
     uint32_t *__restrict__ g_vis = P.vis;
     float2 *__restrict__ g_hit = P.hit;
-    const uint32_t *__restrict__ list0 = P.list[it & 1u][0];
-    const uint32_t *__restrict__ list1 = P.list[it & 1u][1];
-    const uint32_t *__restrict__ list2 = P.list[it & 1u][2];
-    const uint32_t *__restrict__ list3 = P.list[it & 1u][3];
+    // the rays of this iteration, as compacted records in list order (written by k_wf_shade next to the list entries)
+    const size_t cls_stride = (size_t)P.list_cap * kWfShards;
+    const float4 *__restrict__ recA = P.recA + (size_t)((it & 1u) * 4u) * cls_stride;
+    const float4 *__restrict__ recB = P.recB + (size_t)((it & 1u) * 4u) * cls_stride;
+    const uint4 *__restrict__ recC = P.recC + (size_t)((it & 1u) * 4u) * cls_stride;
     const float hit_pad = P.sc.hit_pad;
     const int root = QUANT == 2 ? P.sc.root8 : CRT_WF_BVH4 ? P.sc.root4 : P.sc.root;
     int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
@@ -741,22 +839,23 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     const uint32_t idx = chunk_pos + my;
                     const size_t region = (size_t)cur_shard * P.list_cap;
                     shadow = idx >= sh_e1;
-                    slot = (idx < sh_e0 ? list0[region + idx] : idx < sh_e1 ? list1[region + (idx - sh_e0)]
-                          : idx < sh_e2 ? list2[region + (idx - sh_e1)] : list3[region + (idx - sh_e2)]) & kWfListSlot;
-                    // set up the ray
-                    const float4 ro = g_ray_o[slot];
+                    const size_t g = idx < sh_e0 ? region + idx : idx < sh_e1 ? cls_stride + region + (idx - sh_e0)
+                                   : idx < sh_e2 ? 2u * cls_stride + region + (idx - sh_e1) : 3u * cls_stride + region + (idx - sh_e2);
+                    // set up the ray: the whole record in one round trip
+                    const float4 ro = recA[g], rd = recB[g];
+                    uint4 rc = uint4{0, 0, 0, 0};
+                    if (shadow) rc = recC[g];
                     o = xyz(ro); excl = f_bits(ro.w);
+                    d = xyz(rd);
                     active = true;
                     if (shadow) {
-                        const float4 sd = g_sh_d[slot];
-                        d = xyz(sd); t_max = sd.w;
-                        b_index = g_vis[slot];                    // the light's primitive index
-                        b_slot = slot_of_index[b_index];
+                        slot = rc.x; t_max = rd.w;
+                        b_index = rc.y;                           // the light's primitive index and slot
+                        b_slot = rc.z;
                     } else {
-                        const float4 rd = g_ray_d[slot];
-                        d = xyz(rd);
+                        slot = f_bits(rd.w) & kWfListSlot;
                         t_max = CRT_INFINITY; b_index = kNoHit; b_slot = kNoHit;
-                        if (f_bits(rd.w) != 0u) active = false;   // non-finite ray, already resolved by k_wf_shade
+                        if (f_bits(rd.w) & kWfListAlsoExt) active = false;   // non-finite ray, already resolved by k_wf_shade
                         else if (nprim == 0u) { g_hit[slot] = float2{t_max, bits_f(kNoHit)}; active = false; }
                     }
                     b_slot_in = b_slot;
@@ -792,7 +891,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
             // t_max shrinks a little later.
             if (active && node < 0 && pend == 0 && sp > 0) {
                 pend = node;
-                sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
+                sp--; node = stack_pop(stk, ovf, ovl, sp);
             }
 #endif
             const bool inner = active && node >= 0 && node != kNoNode;
@@ -819,7 +918,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     }
                     if (COUNT) c_prims += cnt;
                     if (from_pend) pend = 0;
-                    else if (sp > 0) { sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl]; }
+                    else if (sp > 0) { sp--; node = stack_pop(stk, ovf, ovl, sp); }
                     else node = kNoNode;
                     bool done = false;
                     if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
@@ -873,7 +972,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                         CRT_PUSH(k7, r7) CRT_PUSH(k6, r6) CRT_PUSH(k5, r5) CRT_PUSH(k4, r4) CRT_PUSH(k3, r3) CRT_PUSH(k2, r2) CRT_PUSH(k1, r1)
                         node = r0;
                     } else if (sp > 0) {
-                        sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
+                        sp--; node = stack_pop(stk, ovf, ovl, sp);
                     } else {
                         node = kNoNode;                                  // nothing left to walk ...
                         if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
@@ -944,7 +1043,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                         if (k1 < 3.0e38f) { if (sp < kWfStack) stk[sp * 64] = r1; else ovf[(size_t)(sp - kWfStack) * ovl] = r1; sp++; }
                         node = r0;
                     } else if (sp > 0) {
-                        sp--; node = sp < kWfStack ? stk[sp * 64] : ovf[(size_t)(sp - kWfStack) * ovl];
+                        sp--; node = stack_pop(stk, ovf, ovl, sp);
                     } else {
                         node = kNoNode;                                  // nothing left to walk ...
                         if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
