@@ -65,6 +65,29 @@ constexpr int kTraceChunk = 128;            // list entries a wave reserves per 
 constexpr int kRefillAt = CRT_WF_REFILL;    // refill when at least this many lanes are idle
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Streams that are touched once per iteration (the pool's per-slot state, ray lists and records, staging) are loaded and
+// stored NON-TEMPORALLY: a shade launch moves ~1 GB through an XCD's 4 MB of L2 while the other pipe's traversal kernel
+// lives on the scene's nodes and triangles staying there.
+#ifndef CRT_WF_NT
+#define CRT_WF_NT 1
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+#if CRT_WF_NT
+__device__ __forceinline__ float4 ldnt(const float4 *p) { const v4f v = __builtin_nontemporal_load((const v4f *)p); return float4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ uint4 ldnt(const uint4 *p) { const v4u v = __builtin_nontemporal_load((const v4u *)p); return uint4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ float2 ldnt(const float2 *p) { const v2f v = __builtin_nontemporal_load((const v2f *)p); return float2{v.x, v.y}; }
+__device__ __forceinline__ uint32_t ldnt(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stnt(float4 *p, float4 v) { __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (v4f *)p); }
+__device__ __forceinline__ void stnt(uint4 *p, uint4 v) { __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p); }
+__device__ __forceinline__ void stnt(float2 *p, float2 v) { __builtin_nontemporal_store(v2f{v.x, v.y}, (v2f *)p); }
+__device__ __forceinline__ void stnt(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ T ldnt(const T *p) { return *p; }
+template <class T> __device__ __forceinline__ void stnt(T *p, T v) { *p = v; }
+#endif
 __device__ __forceinline__ uint32_t prefix_popc(unsigned long long mask, uint32_t lane)
 {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -114,7 +137,6 @@ __device__ __forceinline__ LightRec load_light(const DevScene &S, uint32_t li)
     LightRec r;
     r.A = float4{0.0f, 0.0f, 0.0f, 0.0f}; r.B = r.A; r.C = r.A; r.D = r.A; r.slot = kNoHit; r.pdf_area = 0.0f;
     if (UNIFORM) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(4))) v4f *cptr4;
         typedef const __attribute__((address_space(4))) uint32_t *cptr1;
         auto ld = [](cptr4 p) { const v4f v = *p; return float4{v.x, v.y, v.z, v.w}; };
@@ -204,7 +226,7 @@ __device__ __forceinline__ ShadowOut light_sample(const WfParams &P, const Light
         if (COUNT) cn.hits++;
         const f4 nee = nee_term(S, L, pos, ldir, t_l, cos_theta, sample_spectrum(S, f_bits(L.L0.w), wl));
         f4 c = (brdf * nee) * beta;          // added to radiance iff the light is visible
-        P.nee[slot] = float4{c.x, c.y, c.z, c.w};
+        stnt(&P.nee[slot], float4{c.x, c.y, c.z, c.w});
         if (FINISH) {                        // (k_wf_finish traces from the slot arrays; the pool's
             P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};   //  traversal kernel from the ray records)
             P.vis[slot] = include;
@@ -240,8 +262,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     float2 h = float2{0.0f, 0.0f};
     uint32_t vis_in = 0;
     if (in_pool) {
-        misc = P.misc[slot]; v_ro = P.ray_o[slot]; v_rd = P.ray_d[slot]; v_beta = P.beta[slot];
-        v_rad = P.radiance[slot]; rs = P.rng[slot]; h = P.hit[slot]; vis_in = P.vis[slot]; v_nee = P.nee[slot];
+        misc = ldnt(&P.misc[slot]); v_ro = ldnt(&P.ray_o[slot]); v_rd = ldnt(&P.ray_d[slot]); v_beta = ldnt(&P.beta[slot]);
+        v_rad = ldnt(&P.radiance[slot]); rs = ldnt(&P.rng[slot]); h = ldnt(&P.hit[slot]); vis_in = ldnt(&P.vis[slot]); v_nee = ldnt(&P.nee[slot]);
     }
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
     bool alive = in_pool && (R.flags & kWfAlive);
@@ -393,7 +415,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             const uint32_t tile = pp >> 6, l = pp & 63u;
             const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
             f3 c = spectral_to_xyz(S, R.radiance, wl);
-            P.staging[(R.flags >> kWfBatchShift) & (kWfRing - 1u)][(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx] = float4{c.x, c.y, c.z, 0.0f};
+            stnt(&P.staging[(R.flags >> kWfBatchShift) & (kWfRing - 1u)][(size_t)sample_off * ((size_t)P.tw * P.th) + (size_t)ly * P.tw + lx], float4{c.x, c.y, c.z, 0.0f});
             alive = false;
             if (COUNT) cn.paths++;
         }
@@ -504,7 +526,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     uint32_t resolved = 0u;
     if (in_pool) {
         if (alive) {
-            P.ray_o[slot] = float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)};
+            stnt(&P.ray_o[slot], float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)});
             // A non-finite ray (e.g. refract at the numerical edge of total reflection) is decided
             // by the reference loop in its own order; do that here and flag the ray as resolved
             // so the traversal kernel stays free of the fallback.
@@ -514,12 +536,12 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                 if (COUNT) cn.prims += S.nprim;
                 resolved = 1u;
             }
-            P.ray_d[slot] = float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)};
-            P.beta[slot] = float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w};
-            P.radiance[slot] = float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w};
-            P.rng[slot] = uint4{R.rng.x, R.rng.y, R.rng.z, R.rng.w};
+            stnt(&P.ray_d[slot], float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)});
+            stnt(&P.beta[slot], float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w});
+            stnt(&P.radiance[slot], float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w});
+            stnt(&P.rng[slot], uint4{R.rng.x, R.rng.y, R.rng.z, R.rng.w});
         }
-        P.misc[slot] = uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)};
+        stnt(&P.misc[slot], uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)});
     }
     return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, (R.flags >> kWfBatchShift) & (kWfRing - 1u),
                     R.ray_o, R.exclude, R.ray_d, resolved, out_sd, out_tl, out_lindex, out_lslot};
@@ -607,7 +629,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         slot = 0; in_pool = false;
         const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
         if (cls < 4u && e < pv.n[cls]) {
-            const uint32_t entry = P.list[lbuf ^ 1u][cls][region + e];
+            const uint32_t entry = ldnt(&P.list[lbuf ^ 1u][cls][region + e]);
             slot = entry & kWfListSlot;
             in_pool = !(entry & kWfListAlsoExt);                 // else reached through its extension ray
         }
@@ -676,19 +698,19 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         if (emit_ext) {
             const uint32_t c = cl0 ? 0u : 1u;
             const size_t e = region + (cl0 ? b0 + prefix_popc(m0, lane) : b1 + prefix_popc(m1, lane));
-            P.list[lbuf][c][e] = slot;
+            stnt(&P.list[lbuf][c][e], slot);
             const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + e;
-            P.recA[g] = float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)};
-            P.recB[g] = float4{so.d.x, so.d.y, so.d.z, bits_f(slot | (so.resolved ? kWfListAlsoExt : 0u))};
+            stnt(&P.recA[g], float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)});
+            stnt(&P.recB[g], float4{so.d.x, so.d.y, so.d.z, bits_f(slot | (so.resolved ? kWfListAlsoExt : 0u))});
         }
         if (emit_sh) {
             const uint32_t c = cl2 ? 2u : 3u;
             const size_t e = region + (cl2 ? b2 + prefix_popc(m2, lane) : b3 + prefix_popc(m3, lane));
-            P.list[lbuf][c][e] = slot | (emit_ext ? kWfListAlsoExt : 0u);
+            stnt(&P.list[lbuf][c][e], slot | (emit_ext ? kWfListAlsoExt : 0u));
             const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + e;
-            P.recA[g] = float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)};
-            P.recB[g] = float4{so.sd.x, so.sd.y, so.sd.z, so.t_l};
-            P.recC[g] = uint4{slot, so.l_index, so.l_slot, 0u};
+            stnt(&P.recA[g], float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)});
+            stnt(&P.recB[g], float4{so.sd.x, so.sd.y, so.sd.z, so.t_l});
+            stnt(&P.recC[g], uint4{slot, so.l_index, so.l_slot, 0u});
         }
     }
     if (COUNT) {
@@ -842,9 +864,9 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     const size_t g = idx < sh_e0 ? region + idx : idx < sh_e1 ? cls_stride + region + (idx - sh_e0)
                                    : idx < sh_e2 ? 2u * cls_stride + region + (idx - sh_e1) : 3u * cls_stride + region + (idx - sh_e2);
                     // set up the ray: the whole record in one round trip
-                    const float4 ro = recA[g], rd = recB[g];
+                    const float4 ro = ldnt(&recA[g]), rd = ldnt(&recB[g]);
                     uint4 rc = uint4{0, 0, 0, 0};
-                    if (shadow) rc = recC[g];
+                    if (shadow) rc = ldnt(&recC[g]);
                     o = xyz(ro); excl = f_bits(ro.w);
                     d = xyz(rd);
                     active = true;
@@ -924,8 +946,8 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     if (shadow && b_slot != b_slot_in) done = true;    // any-hit: something beats the light
                     else if (node == kNoNode && pend == 0) done = true;
                     if (done) {
-                        if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                        else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                        if (shadow) stnt(&g_vis[slot], (b_slot == b_slot_in) ? 1u : 0u);
+                        else stnt(&g_hit[slot], float2{t_max, bits_f(b_slot)});
                         active = false;
                     }
                 }
@@ -976,8 +998,8 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     } else {
                         node = kNoNode;                                  // nothing left to walk ...
                         if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
-                            if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                            else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                            if (shadow) stnt(&g_vis[slot], (b_slot == b_slot_in) ? 1u : 0u);
+                            else stnt(&g_hit[slot], float2{t_max, bits_f(b_slot)});
                             active = false;
                         }
                     }
@@ -1047,8 +1069,8 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     } else {
                         node = kNoNode;                                  // nothing left to walk ...
                         if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
-                            if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                            else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                            if (shadow) stnt(&g_vis[slot], (b_slot == b_slot_in) ? 1u : 0u);
+                            else stnt(&g_hit[slot], float2{t_max, bits_f(b_slot)});
                             active = false;
                         }
                     }
@@ -1085,8 +1107,8 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     } else {
                         node = kNoNode;                                  // stack empty ...
                         if (pend == 0) {                                 // ... and no postponed leaf: this ray is finished
-                            if (shadow) g_vis[slot] = (b_slot == b_slot_in) ? 1u : 0u;
-                            else g_hit[slot] = float2{t_max, bits_f(b_slot)};
+                            if (shadow) stnt(&g_vis[slot], (b_slot == b_slot_in) ? 1u : 0u);
+                            else stnt(&g_hit[slot], float2{t_max, bits_f(b_slot)});
                             active = false;
                         }
                     }
@@ -1195,7 +1217,7 @@ __global__ __launch_bounds__(64) void k_wf_resolve(const WfParams P, uint32_t la
     f3 acc = f3{a4.x, a4.y, a4.z};
     const float4 *__restrict__ staging = P.staging[P.batch_id];
     for (uint32_t s = 0; s < P.n_samples; s++) {
-        const float4 v = staging[(size_t)s * npix + pix];
+        const float4 v = ldnt(&staging[(size_t)s * npix + pix]);
         acc = acc + f3{v.x, v.y, v.z};                           // :108, in sample order
     }
     P.accum[pix] = float4{acc.x, acc.y, acc.z, a4.w};
