@@ -245,10 +245,18 @@ struct ShadeOut {
     f3 sd; float t_l; uint32_t l_index, l_slot;
 };
 
+// Phase clock of the probe build (make EXTRA=-DCRT_WF_PROBE OUT=.../tune_probe.so, tools/shade_probe.py): everything
+// issued so far has arrived, then the cycle counter.  Compiles to nothing otherwise.
+#ifdef CRT_WF_PROBE
+#define CRT_PROBE(tp, k) if (tp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (tp)[k] = __builtin_readcyclecounter(); }
+#else
+#define CRT_PROBE(tp, k)
+#endif
+
 // One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
 // driven by k_wf_finish (no re-arming from the work queue; the caller traces the emitted rays itself).
 template <bool COUNT, bool FINISH>
-__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, uint32_t my_shard, ShadeCnt &cn)
+__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, uint32_t my_shard, ShadeCnt &cn, unsigned long long *tp = nullptr)
 {
     const DevScene &S = P.sc;
     PathRegs R;
@@ -265,6 +273,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         misc = ldnt(&P.misc[slot]); v_ro = ldnt(&P.ray_o[slot]); v_rd = ldnt(&P.ray_d[slot]); v_beta = ldnt(&P.beta[slot]);
         v_rad = ldnt(&P.radiance[slot]); rs = ldnt(&P.rng[slot]); h = ldnt(&P.hit[slot]); vis_in = ldnt(&P.vis[slot]); v_nee = ldnt(&P.nee[slot]);
     }
+    CRT_PROBE(tp, 1)
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
     bool alive = in_pool && (R.flags & kWfAlive);
     bool emit_ext = false, emit_sh = false;
@@ -276,6 +285,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     const bool has_hit = alive && !(R.flags & kWfDying) && h_slot != kNoHit;
     float4 hA = float4{0, 0, 0, 0}, hB = hA, hC = hA, hD = hA;
     if (has_hit) { hA = S.prim[3 * (size_t)h_slot + 0]; hB = S.prim[3 * (size_t)h_slot + 1]; hC = S.prim[3 * (size_t)h_slot + 2]; hD = S.primD[h_slot]; }
+    CRT_PROBE(tp, 2)
 
     if (alive) {
         R.ray_o = xyz(v_ro); R.exclude = f_bits(v_ro.w);
@@ -421,6 +431,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
     }
 
+    CRT_PROBE(tp, 3)
     if (!FINISH) {
     // 3. re-arm dead slots with the next (sample, pixel) work item.  A queue's work range is split into kWfShards
     //    contiguous sub-ranges with their own cursors, and several queues (batches) can be listed, oldest first.
@@ -522,6 +533,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
 
     }
 
+    CRT_PROBE(tp, 4)
     // 4. write the slot back
     uint32_t resolved = 0u;
     if (in_pool) {
@@ -661,7 +673,16 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         }
     }
     ShadeCnt cn;
-    const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, my_shard, cn);
+#ifdef CRT_WF_PROBE
+    // one wave in 256 clocks its phases into counters 8..14 (more would serialise on the counters' lines)
+    unsigned long long tpa[8];
+    unsigned long long *tp = (!COUNT && P.tail_bound == 0u && (blockIdx.x & 255u) == 7u) ? tpa : nullptr;
+    tpa[0] = __builtin_readcyclecounter();
+#else
+    unsigned long long *tp = nullptr;
+#endif
+    const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, my_shard, cn, tp);
+    CRT_PROBE(tp, 5)
     const bool emit_ext = so.emit_ext, ext_primary = so.ext_primary, emit_sh = so.emit_sh, sh_primary = so.sh_primary;
     {
         const uint32_t lane = lane_id();
@@ -722,6 +743,13 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         wave_add(ctl->counters + CRT_CNT_PRIMS, cn.prims);
         wave_add(ctl->counters + CRT_CNT_WALKED, cn.walk);
     }
+#ifdef CRT_WF_PROBE
+    CRT_PROBE(tp, 6)
+    if (tp && lane_id() == 0) {
+        for (int k = 0; k < 6; k++) atomicAdd(ctl->counters + 8 + k, tp[k + 1] - tp[k]);
+        atomicAdd(ctl->counters + 14, 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ trace
