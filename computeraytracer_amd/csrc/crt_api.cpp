@@ -1149,9 +1149,13 @@ int wf_finish_all(crt_ctx *c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         unsigned long long pc[CRT_NCOUNTERS_DEV];
         for (int p = 0; p < K; p++) {
-            HIPCHK(c, hipMemcpy(pc, &c->w_ctl[p].p->counters[0], sizeof pc, hipMemcpyDeviceToHost));
+            {
+                unsigned long long sh[kWfShards][CRT_NCOUNTERS_DEV];
+                HIPCHK(c, hipMemcpy(sh, &c->w_ctl[p].p->counters[0][0], sizeof sh, hipMemcpyDeviceToHost));
+                for (int k = 0; k < CRT_NCOUNTERS_DEV; k++) { pc[k] = 0; for (uint32_t s_ = 0; s_ < kWfShards; s_++) pc[k] += sh[s_][k]; }
+            }
             for (int k = 0; k < 8; k++) c->probes[k] += pc[8 + k];
-            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
+            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0][0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV * kWfShards));
         }
     }
 #endif
@@ -1162,10 +1166,14 @@ int wf_finish_all(crt_ctx *c)
         HIPCHK(c, hipMemcpy(tot, c->d_counters.p, sizeof tot, hipMemcpyDeviceToHost));
         unsigned long long pc[CRT_NCOUNTERS_DEV];
         for (int p = 0; p < K; p++) {
-            HIPCHK(c, hipMemcpy(pc, &c->w_ctl[p].p->counters[0], sizeof pc, hipMemcpyDeviceToHost));
+            {
+                unsigned long long sh[kWfShards][CRT_NCOUNTERS_DEV];
+                HIPCHK(c, hipMemcpy(sh, &c->w_ctl[p].p->counters[0][0], sizeof sh, hipMemcpyDeviceToHost));
+                for (int k = 0; k < CRT_NCOUNTERS_DEV; k++) { pc[k] = 0; for (uint32_t s_ = 0; s_ < kWfShards; s_++) pc[k] += sh[s_][k]; }
+            }
             for (int k = 0; k < CRT_NCOUNTERS; k++) tot[k] += pc[k];
             for (int k = 0; k < 8; k++) c->probes[k] += pc[8 + k];
-            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV));
+            HIPCHK(c, hipMemset(&c->w_ctl[p].p->counters[0][0], 0, sizeof(unsigned long long) * CRT_NCOUNTERS_DEV * kWfShards));
         }
         HIPCHK(c, hipMemcpy(c->d_counters.p, tot, sizeof tot, hipMemcpyHostToDevice));
     }

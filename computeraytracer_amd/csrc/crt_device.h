@@ -103,7 +103,7 @@ static_assert(sizeof(WfShard) == 256, "two lines per shard: the list counters an
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
     WfShard shard[4][kWfShards];     // ring-indexed by iteration & 3 (it-1 is read, it written, it+1 zeroed)
-    unsigned long long counters[CRT_NCOUNTERS_DEV];
+    unsigned long long counters[kWfShards][CRT_NCOUNTERS_DEV];   // sharded like everything the waves add to (a shard = one 128-byte line); the host sums
     uint32_t side_count[kWfRing];    // paths moved to the side pool, per batch id
     uint32_t dropped;                // paths a capacity guard had to leave behind (side pool full, bounce guard of
                                      // k_wf_finish): must stay 0 -- the host turns anything else into CRT_EDEVICE

@@ -735,19 +735,19 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         }
     }
     if (COUNT) {
-        wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
-        wave_add(ctl->counters + CRT_CNT_BOUNCES, cn.bounces);
-        wave_add(ctl->counters + CRT_CNT_SHADOW, cn.shadow);
-        wave_add(ctl->counters + CRT_CNT_HITS, cn.hits);
-        wave_add(ctl->counters + CRT_CNT_PATHS, cn.paths);
-        wave_add(ctl->counters + CRT_CNT_PRIMS, cn.prims);
-        wave_add(ctl->counters + CRT_CNT_WALKED, cn.walk);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_RAYS, cn.rays);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_BOUNCES, cn.bounces);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_SHADOW, cn.shadow);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_HITS, cn.hits);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_PATHS, cn.paths);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_PRIMS, cn.prims);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_WALKED, cn.walk);
     }
 #ifdef CRT_WF_PROBE
     CRT_PROBE(tp, 6)
     if (tp && lane_id() == 0) {
-        for (int k = 0; k < 6; k++) atomicAdd(ctl->counters + 8 + k, tp[k + 1] - tp[k]);
-        atomicAdd(ctl->counters + 14, 1ull);
+        for (int k = 0; k < 6; k++) atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 8 + k, tp[k + 1] - tp[k]);
+        atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 14, 1ull);
     }
 #endif
 }
@@ -1146,13 +1146,13 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
         }
     }
     if (COUNT) {
-        wave_add(ctl->counters + CRT_CNT_NODES, c_nodes);
-        wave_add(ctl->counters + CRT_CNT_PRIMS, c_prims);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_NODES, c_nodes);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_PRIMS, c_prims);
         if (lane == 0) {
-            atomicAdd(ctl->counters + 8, (unsigned long long)d_inner_it); atomicAdd(ctl->counters + 9, (unsigned long long)d_inner_act);
-            atomicAdd(ctl->counters + 10, (unsigned long long)d_leaf_it); atomicAdd(ctl->counters + 11, (unsigned long long)d_leaf_act);
-            atomicAdd(ctl->counters + 12, (unsigned long long)d_prim_it); atomicAdd(ctl->counters + 13, (unsigned long long)d_scans); atomicAdd(ctl->counters + 14, (unsigned long long)d_refill);
-            atomicAdd(ctl->counters + 15, (unsigned long long)d_refill_lanes);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 8, (unsigned long long)d_inner_it); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 9, (unsigned long long)d_inner_act);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 10, (unsigned long long)d_leaf_it); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 11, (unsigned long long)d_leaf_act);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 12, (unsigned long long)d_prim_it); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 13, (unsigned long long)d_scans); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 14, (unsigned long long)d_refill);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 15, (unsigned long long)d_refill_lanes);
         }
     }
 }
@@ -1222,14 +1222,14 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFini
     if (alive) atomicAdd(&ctl->dropped, 1u);     // the bounce guard ended a live path (cannot happen: MAXDEPTH is 100): reported
 
     if (COUNT) {
-        wave_add(ctl->counters + CRT_CNT_RAYS, cn.rays);
-        wave_add(ctl->counters + CRT_CNT_BOUNCES, cn.bounces);
-        wave_add(ctl->counters + CRT_CNT_SHADOW, cn.shadow);
-        wave_add(ctl->counters + CRT_CNT_HITS, cn.hits);
-        wave_add(ctl->counters + CRT_CNT_PATHS, cn.paths);
-        wave_add(ctl->counters + CRT_CNT_PRIMS, cn.prims + c_prims);
-        wave_add(ctl->counters + CRT_CNT_WALKED, cn.walk);
-        wave_add(ctl->counters + CRT_CNT_NODES, c_nodes);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_RAYS, cn.rays);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_BOUNCES, cn.bounces);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_SHADOW, cn.shadow);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_HITS, cn.hits);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_PATHS, cn.paths);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_PRIMS, cn.prims + c_prims);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_WALKED, cn.walk);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_NODES, c_nodes);
     }
 }
 
