@@ -7,6 +7,8 @@ import time
 
 import numpy as np
 
+sys.path.insert(0, '.')
+
 from computeraytracer_amd import Renderer, cornell
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
