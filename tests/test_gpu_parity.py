@@ -163,6 +163,34 @@ def test_mixed_categories_with_glass(renderer, orc):
     assert_same_image(acc, rgba, acc_o, rgba_o)
 
 
+def _three_lights_scene(w, h):
+    """Cornell with two more light patches (another emission spectrum, other sizes): the light is chosen per lane, its
+    record and its primitive's record are gathered per lane (the one-light scalar path does not apply), and
+    `lights[emission_index]` (sic) clamps to the LAST light instead of the only one."""
+    from computeraytracer_amd import scene as S
+    c = S.cornell(w, h)
+    idx = c.spectrum_index
+    extra = S.make_primitives([0, 0], [[2.0, 180.0, 150.0], [300.0, 2.0, 60.0]], [[0.0, 120.0, 0.0], [90.0, 0.0, 0.0]],
+                              [[0.0, 0.0, 160.0], [0.0, 0.0, 70.0]], [idx["lightAlt"], idx["light"]], [idx["white"]] * 2,
+                              [S.TYPE_INDEX["light"]] * 2, first_index=len(c.primitives))
+    prims = np.zeros(len(c.primitives) + 2, S.PRIM_DTYPE)
+    prims[:-2] = c.primitives
+    prims[-2:] = extra
+    lights = S.lights_of(prims)
+    assert len(lights) == 3
+    return S.PackedScene(prims, lights, c.camera, c.spectra, c.cie)
+
+
+def test_several_lights(renderer, orc):
+    ps = _three_lights_scene(128, 96)
+    acc_o, rgba_o, cnt_o = orc.Scene.from_packed(ps).render(6)
+    for pipeline in (1, 0):
+        renderer.set_option("pipeline", pipeline)
+        acc, rgba = render(renderer, ps, 6)
+        assert_same_image(acc, rgba, acc_o, rgba_o)
+    renderer.set_option("pipeline", 1)
+
+
 def test_no_primitives(renderer, orc):
     """Empty primitive array (only the light record): every ray misses."""
     from computeraytracer_amd import cornell, scene as S
