@@ -159,7 +159,7 @@ struct crt_ctx {
     int wf_chunk = 1;               // iterations per status record at most
     int wf_ahead = 3;               // iterations in flight per pipe before the pump waits for a status
     int wf_ring = 32;               // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
-    int wf_pool_spp = 4;            // automatic pool size: at least this many path slots per tile pixel (within 1 M .. 8 M)
+    int wf_pool_spp = 8;            // automatic pool size: at least this many path slots per tile pixel (within 1 M .. 24 M)
     double wf_feed = 1.0;           // pump: weight of the work the iterations in flight are expected to consume
     WfRun *run = nullptr;           // pipeline state between calls
     uint32_t wf_finish_at = 32768;  // paths of the oldest batch left (per pipe) at which they move to the side pool; 0 = never
@@ -644,11 +644,14 @@ WfConfig wf_config(crt_ctx *c, uint32_t n)
     g.npix_padded = g.tiles_x * g.tiles_y * 64u;
     g.npix = (size_t)c->tw * c->th;
     g.work_total = (unsigned long long)n * g.npix_padded;
-    // pool: between 1 M and 8 M slots, about a quarter of a LARGE batch's paths (measured best on S2 with several
-    // batches in flight: whole frame and 1/2, 1/4, 1/8 shares, profiles/r01_steady_pool.log); a stream of small
-    // batches shares the pool, so it is sized by the tile, not by one call's samples
+    // pool: between 1 M and 24 M slots, about a quarter of a LARGE batch's paths and at least wf_pool_spp (8) per tile
+    // pixel; a stream of small batches shares the pool, so it is sized by the tile, not by one call's samples.  (8 M was
+    // the cap while the pool's streams still washed the scene out of the L2 with every launch; with them non-temporal a
+    // launch costs what its rays cost plus a fixed ramp-up, tail and gap, and larger launches amortise those:
+    // profiles/r02_pool_sweep.txt, r02_pool_bench.txt -- 8 / 16 / 24 M slots: 63.9 / 61.4 / 60.5 ms per 64-spp step,
+    // 1.035 / 1.001 / 1.007 ms per 1-spp step.)
     const unsigned long long per_pixel = std::max<unsigned long long>(g.work_total / 4u, (unsigned long long)g.npix_padded * (unsigned long long)c->wf_pool_spp);
-    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(1u << 23, std::max<unsigned long long>(1u << 20, per_pixel));
+    uint32_t P = c->wf_pool ? c->wf_pool : (uint32_t)std::min<unsigned long long>(3u << 23, std::max<unsigned long long>(1u << 20, per_pixel));
     // (a pool may exceed one batch's work: several batches share it, but never more than the ring holds)
     const unsigned long long most = g.work_total * (unsigned long long)std::max(1u, std::min<uint32_t>(c->wf_ring, kWfRing) - 1u);
     if ((unsigned long long)P > most) P = (uint32_t)most;

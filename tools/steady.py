@@ -16,8 +16,8 @@ def t(calls=24, n=2):
 for name, bands in (('frame', None), ('1/2 bands', (8, 2, 1)), ('1/4 bands', (8, 4, 1)), ('1/8 bands', (8, 8, 3))):
     if bands: r.set_row_bands(*bands)
     out = []
-    for opts in ({}, {'wf_pool_spp': 8}, {'wf_pool_spp': 16}, {'wf_cohort': 128}, {'wf_ahead': 5}):
+    for opts in ({}, {'wf_pool_spp': 4}, {'wf_pool_spp': 16}, {'wf_cohort': 128}, {'wf_ahead': 5}):
         for k, v in opts.items(): r.set_option(k, v)
         out.append('%s: %.2f' % (','.join('%s=%d' % kv for kv in opts.items()) or 'default', t()))
-        for k, v in {'wf_pool_spp': 4, 'wf_cohort': 16, 'wf_ahead': 3}.items(): r.set_option(k, v)
+        for k, v in {'wf_pool_spp': 8, 'wf_cohort': 16, 'wf_ahead': 3}.items(): r.set_option(k, v)
     print(name, ' | '.join(out), flush=True)
