@@ -173,7 +173,7 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
 
 /* Tuning knobs.  "spp_per_launch": samples fused per batch (0 = default);
  * "pipeline": 1 = wavefront (default), 0 = single megakernel; "wf_pool": path slots
- * (0 = auto: "wf_pool_spp" slots per tile pixel, 1 M..8 M); "wf_waves_per_cu": persistent traversal
+ * (0 = auto: a quarter of a batch, at least "wf_pool_spp" (8) slots per tile pixel, 1 M..24 M); "wf_waves_per_cu": persistent traversal
  * waves per CU and pipe; "wf_pipes": sub-pools on separate streams (1..4); "wf_defer": 0 = every crt_trace
  * call runs its paths to the end; "wf_ring" (2..32 batches in flight), "wf_cohort" (samples per batch that small calls are merged up to), "wf_chunk" (iterations enqueued at
  * a time), "wf_ahead" (iterations in flight per pipe before the call waits), "wf_feed_pct", "wf_finish_at",
