@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--spp", type=int, default=64, help="samples per step (BASELINE config 3: 64)")
     ap.add_argument("--soup-tris", type=int, default=10_000_000)
     ap.add_argument("--band", type=int, default=8, help="rows per interleaved band for N>1 (0 = contiguous strips)")
+    ap.add_argument("--accel", default="bvh2", choices=["bvh2", "lbvh"],
+                    help="tree builder: bvh2 = binned SAH on the host (default), lbvh = crt_build_accel(LBVH), all on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="crt_set_option before the run (e.g. wf_pipes=1 for the single-pipe profile); noted in config")
@@ -118,7 +120,7 @@ def main():
     sf = (HostStagedStripFrame if backend != "nccl" else StripFrame)(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
     sf.apply(r)
     t0 = time.time()
-    r.build_accel("bvh2")
+    r.build_accel(args.accel)
     t_build = time.time() - t0
     # strips live in torch tensors (padded to equal size) so RCCL can gather them
     r.bind_output(sf.accum.data_ptr(), sf.rgba.data_ptr())
@@ -172,7 +174,7 @@ def main():
     if full_check and world > 1 and rank == 0:
         acc_all, rgba_all = sf.image()
         ref = Renderer(local_rank)
-        ref.upload(ps).build_accel("bvh2").frame((args.warmup + args.steps) * args.spp).sync()
+        ref.upload(ps).build_accel(args.accel).frame((args.warmup + args.steps) * args.spp).sync()
         same = bool((torch.from_numpy(ref.read_accum()).to(dev) == acc_all).all()) and \
             bool((torch.from_numpy(ref.read_rgba8()).to(dev) == rgba_all).all())
         print(f"[check] gathered frame identical to a single-GPU render: {same}", file=sys.stderr, flush=True)
@@ -252,7 +254,9 @@ def main():
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
                        "partition": (f"rows dealt to {world} GPUs in bands of {args.band}" if world > 1 and args.band else f"{world} horizontal strip(s)")
                                     + ", scene replicated, all_gather of the rgba8 strips per step",
-                       "accel": "binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s; crt_build_accel(LBVH) builds on the GPU in milliseconds)" % t_build,
+                       "accel": ("binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s; crt_build_accel(LBVH) builds on the GPU in milliseconds)" % t_build)
+                                if args.accel == "bvh2" else
+                                ("LBVH built, collapsed to 4-wide 64-byte quantised nodes and leaf-ordered on the GPU (crt_build_accel(LBVH): %.3f s)" % t_build),
                        "options": args.opt,
                        "pipelining": "steps are software-pipelined like a display loop: frame() returns with its batch in flight "
                                      "(up to 32 batches, retired in order under the following frames); the gather after frame k ships the "
