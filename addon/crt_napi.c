@@ -48,6 +48,8 @@ struct job;
 typedef struct slot {
     crt_ctx *ctx;
     struct job *head, *tail;     /* pending jobs, head = the one running */
+    napi_ref self;               /* strong reference to the handle while jobs are pending: a promise does not keep the
+                                    external alive, and `traceAsync(create(0), n)` must not be collected mid-job */
 } slot;
 
 static void finalize_ctx(napi_env env, void *data, void *hint)
@@ -55,7 +57,8 @@ static void finalize_ctx(napi_env env, void *data, void *hint)
     (void)env; (void)hint;
     slot *s = (slot *)data;
     if (s) {
-        if (s->ctx && !s->head) crt_destroy(s->ctx);   /* (a job still running keeps the context alive; leaked at exit) */
+        /* (unreachable with jobs pending: `self` holds the handle until the queue is empty) */
+        if (s->ctx) crt_destroy(s->ctx);
         free(s);
     }
 }
@@ -429,8 +432,10 @@ static void job_complete(napi_env env, napi_status status, void *data)
     napi_delete_async_work(env, j->work);
     /* the next job of this context */
     sl->head = j->next;
-    if (!sl->head) sl->tail = NULL;
-    else napi_queue_async_work(env, sl->head->work);
+    if (!sl->head) {
+        sl->tail = NULL;
+        if (sl->self) { napi_ref r = sl->self; sl->self = NULL; napi_delete_reference(env, r); }   /* the handle may go now */
+    } else napi_queue_async_work(env, sl->head->work);
     free(j);
 }
 
@@ -464,7 +469,18 @@ static napi_value start_job(napi_env env, napi_callback_info info, int op)
         return NULL;
     }
     if (sl->tail) { sl->tail->next = j; sl->tail = j; }
-    else { sl->head = sl->tail = j; napi_queue_async_work(env, j->work); }
+    else {
+        if (!sl->self && napi_create_reference(env, argv[0], 1, &sl->self) != napi_ok) {
+            sl->self = NULL;
+            napi_delete_async_work(env, j->work);
+            if (j->ab_ref) napi_delete_reference(env, j->ab_ref);
+            free(j);
+            napi_throw_error(env, NULL, "crt_napi: could not pin the context handle");
+            return NULL;
+        }
+        sl->head = sl->tail = j;
+        napi_queue_async_work(env, j->work);
+    }
     return promise;
 }
 static napi_value js_trace_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_TRACE); }

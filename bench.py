@@ -303,7 +303,7 @@ def kernel_sources_sha256():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "computeraytracer_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".cpp")):     # (crt_api.cpp: the pool size there sets the launch size)
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()

@@ -30,6 +30,7 @@ hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out,
 hipError_t wf_launch_init(const WfParams &P, hipStream_t s);
 hipError_t wf_launch_tea(const WfParams &P, uint32_t *out, hipStream_t s);
 hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s);
+hipError_t wf_launch_gen(const WfParams &P, uint32_t it, hipStream_t s);
 hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks, hipStream_t s);
 hipError_t wf_launch_finish(const WfParams &P, WfFinishSegs G, uint32_t max_paths, hipStream_t s);
 hipError_t wf_launch_resolve(const WfParams &P, uint32_t last_sample, hipStream_t s);
@@ -150,7 +151,7 @@ struct crt_ctx {
     DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing], w_recA, w_recB;
     DevBuf<uint4> w_rng, w_misc, w_recC;
     DevBuf<float2> w_hit;
-    DevBuf<uint32_t> w_vis, w_list_ext, w_tea;
+    DevBuf<uint32_t> w_vis, w_dead, w_tea;
     // up to kMaxPipes half-pools, each its own shade->trace chain on its own stream
     static constexpr int kMaxPipes = 4;
     int wf_pipes = 2;
@@ -500,8 +501,8 @@ constexpr int kStatusRing = crt_ctx::kStatusSlots;
 
 int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uint32_t ring)
 {
-    if (c->w_list_ext.n < list_elems) HIPCHK(c, c->w_list_ext.alloc(list_elems));
-    if (c->w_recA.n < list_elems) HIPCHK(c, c->w_recA.alloc(list_elems));      // the ray records, one per list entry
+    if (c->w_dead.n < list_elems / 8) HIPCHK(c, c->w_dead.alloc(list_elems / 8));   // dead-slot lists: one list's worth per pipe
+    if (c->w_recA.n < list_elems) HIPCHK(c, c->w_recA.alloc(list_elems));      // the ray records = the ray lists
     if (c->w_recB.n < list_elems) HIPCHK(c, c->w_recB.alloc(list_elems));
     if (c->w_recC.n < list_elems) HIPCHK(c, c->w_recC.alloc(list_elems));
     // (each array on its own: after a failed allocation that array reports n == 0 and is retried by the next call)
@@ -730,6 +731,10 @@ int wf_enqueue(crt_ctx *c, int p, uint32_t iters)
     pp.W.tail_bound = pp.tail_bound;
     pp.W.count_alive = r.open.size() > 1 ? 1u : 0u;
     wf_set_queues(c, pp);
+    // Dead slots are listed by the shade launch and re-armed by a k_wf_gen launch behind it while a listed queue may
+    // hold work (the host's view lags the device's: a launch too many finds the queues dry, a launch too few leaves
+    // the slots dead for one more iteration).
+    pp.W.rearm = (pp.tail_bound == 0u && r.work_left) ? 1u : 0u;
     const bool evicted = pp.evict_next != 0;
     for (uint32_t k = 0; k < iters; k++, pp.it++) {
         pp.W.evict_mask = pp.evict_next;
@@ -737,6 +742,7 @@ int wf_enqueue(crt_ctx *c, int p, uint32_t iters)
         HIPCHK(c, wf_launch_shade(pp.W, pp.it, pp.stream));
         if (pp.it > pp.it_first) HIPCHK(c, hipEventRecord(c->ev_status[p][(pp.it - 1u) % kStatusRing], pp.stream));   // (blocking waits fall back on it)
         pp.st_counted[pp.it % kStatusRing] = pp.W.count_alive != 0;
+        if (pp.W.rearm) { HIPCHK(c, wf_launch_gen(pp.W, pp.it, pp.stream)); c->last_launches++; }
         if (pp.evict_next) {                                     // k_wf_finish may start once this launch is through
             for (WfBatch &b : r.open)
                 if ((pp.evict_next >> b.id) & 1u) {
@@ -1234,10 +1240,12 @@ int wf_publish_pending(crt_ctx *c, bool force)
         const uint32_t take = std::min(c->pending, cap);
         if (take < cap && !force && defer && take < cohort) break;      // wait for more calls
         c->pending -= take;
+        const uint32_t published0 = c->published;
         rc = wf_trace_batch(c, take);
         if (rc != CRT_OK) {                                       // what could not be published never happened
             c->sample -= take + c->pending;
             c->pending = 0;
+            c->published = published0;                            // (a failure behind `published += n` drained the pool: those samples are gone too)
         }
     }
     c->in_publish = false;
@@ -1247,12 +1255,12 @@ int wf_publish_pending(crt_ctx *c, bool force)
 // Finish whatever the pipeline still holds (no-op when nothing is in flight).
 int wf_flush(crt_ctx *c)
 {
+    if (c->pending || (c->run && c->run->live)) HIPCHK(c, hipSetDevice(c->device));   // (publishing allocates and launches)
     if (c->pending && !c->in_publish && c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
         int rc = wf_publish_pending(c, true);
         if (rc) return rc;
     }
     if (!c->run || !c->run->live) return CRT_OK;
-    HIPCHK(c, hipSetDevice(c->device));
     int rc = wf_finish_all(c);
     if (rc != CRT_OK) {
         // a failed drive leaves the pool in an unknown state: drain the streams and start afresh next time
@@ -1279,9 +1287,17 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     const uint32_t side_slots = kWfRing * (uint32_t)crt_ctx::kMaxPipes * kWfSideCap;   // side pools first, then the pool
     // A live pool is kept as it is unless this batch wants one more than twice as large or small (e.g. 64-spp calls
     // after 1-spp calls), or the staging buffers are too small.
-    if (r.live && ((unsigned long long)g.P > 2ull * r.P || 2ull * g.P < (unsigned long long)r.P || c->w_staging[0].n < staging_elems)) {
-        int rc = wf_flush(c);
-        if (rc) return rc;
+    // The staging buffers are never reallocated under a live pool (the pipes hold their addresses, batches in flight
+    // their contents): if ANY buffer of the ring is too small for this batch, or the ring would take the buffers past
+    // the 32 GB budget at this batch's size, the pool is run to its end first and set up afresh below.
+    if (r.live) {
+        bool regrow = false;
+        for (uint32_t b = 0; b < r.ring; b++) regrow = regrow || c->w_staging[b].n < staging_elems;
+        if (r.ring > 4u && (double)r.ring * (double)staging_elems * 16.0 > 32.0e9) regrow = true;
+        if ((unsigned long long)g.P > 2ull * r.P || 2ull * g.P < (unsigned long long)r.P || regrow) {
+            int rc = wf_flush(c);
+            if (rc) return rc;
+        }
     }
     const uint32_t pool_slots = r.live ? r.P : g.P;
     const size_t list_elems = r.live ? (size_t)8 * r.list_cap * kWfShards * (size_t)r.K : g.list_per_pipe * (size_t)g.K;
@@ -1319,9 +1335,10 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.ray_o = c->w_ray_o.p; W.ray_d = c->w_ray_d.p; W.sh_d = c->w_sh_d.p; W.beta = c->w_beta.p;
             W.radiance = c->w_radiance.p; W.nee = c->w_nee.p; W.rng = c->w_rng.p; W.misc = c->w_misc.p;
             W.hit = c->w_hit.p; W.vis = c->w_vis.p;
-            for (int b = 0; b < 2; b++)
-                for (int k = 0; k < 4; k++)
-                    W.list[b][k] = c->w_list_ext.p + g.list_per_pipe * (size_t)p + (size_t)(b * 4 + k) * g.list_cap * kWfShards;
+            W.dead = c->w_dead.p + (g.list_per_pipe / 8) * (size_t)p;
+            W.rearm = 0;
+            // k_wf_gen: waves per shard (each takes every gen_blocks-th chunk of 64 dead slots of its shard's list)
+            W.gen_blocks = std::max(1u, std::min(128u, g.list_cap / 64u));
             W.recA = c->w_recA.p + g.list_per_pipe * (size_t)p; W.recB = c->w_recB.p + g.list_per_pipe * (size_t)p;
             W.recC = c->w_recC.p + g.list_per_pipe * (size_t)p;
             for (uint32_t b = 0; b < kWfRing; b++) {
@@ -1467,7 +1484,7 @@ void crt_destroy(crt_ctx *c)
     c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
-    c->w_vis.release(); c->w_list_ext.release(); c->w_recA.release(); c->w_recB.release(); c->w_recC.release(); c->w_tea.release(); c->w_wq.release();
+    c->w_vis.release(); c->w_dead.release(); c->w_recA.release(); c->w_recB.release(); c->w_recC.release(); c->w_tea.release(); c->w_wq.release();
     if (c->pub_stream) (void)hipStreamSynchronize(c->pub_stream);
     for (int f = 0; f < crt_ctx::kFinishStreams; f++) {
         if (c->fin_stream[f]) { (void)hipStreamSynchronize(c->fin_stream[f]); (void)hipStreamDestroy(c->fin_stream[f]); }
@@ -1627,6 +1644,9 @@ int crt_build_accel(crt_ctx *c, int mode)
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = wf_flush(c); if (rc_) return rc_; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // The build releases the scene's device arrays before it allocates the new ones: until it has succeeded there is
+    // no structure to trace against (upload_geometry / build_accel_on_device set accel_mode on success only).
+    c->accel_mode = -1;
     return upload_geometry(c, mode);
 }
 

@@ -80,6 +80,7 @@ struct TraceParams {
 //   list[parity][class]                   slots with an active ray this iteration (ballot/popc compacted)
 //   staging[b] (xyz, -) per (sample, pixel)  finished samples of the batch with id b, summed in sample order by k_wf_resolve
 constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
+constexpr uint32_t kWfHasRad = 1u << 30;   // radiance[slot] holds the path's radiance (else it is still zero: nothing was ever stored)
 // ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
 constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;
 constexpr uint32_t kWfDepthShift = 8, kWfLambdaShift = 16;      // depth: 8 bits, lambda0: 9 bits
@@ -98,7 +99,8 @@ constexpr uint32_t kWfSideCap = 65536;
 // wave-wide load + ballot.
 constexpr uint32_t kWfShards = 64;
 // rays listed by shade per class / fetch cursor of trace / slots still alive after the shade launch, per batch id
-struct WfShard { uint32_t n[4], cur, pad0[27], alive[kWfRing]; };
+// n_dead: slots this shard's shade blocks found or left dead in the launch (k_wf_gen re-arms them by whole waves)
+struct WfShard { uint32_t n[4], cur, n_dead, pad0[26], alive[kWfRing]; };
 static_assert(sizeof(WfShard) == 256, "two lines per shard: the list counters and cursor, the per-batch counts");
 struct WfWork { uint32_t cur, pad[31]; };                    // next work item of this shard's range
 struct WfCtl {                       // device control block, one per context
@@ -155,13 +157,17 @@ struct WfParams {
     uint4 *rng, *misc;
     float2 *hit;
     uint32_t *vis;
-    uint32_t *list[2][4];            // ray lists: [iteration parity][class: camera, bounce, shadow of camera hit, shadow]
-    // The rays themselves as compacted records, one per list entry at [(parity*4 + class) * list_cap*kWfShards + shard*list_cap + i]:
+    // The rays of an iteration as compacted records, [iteration parity][class: camera, bounce, shadow of camera hit, shadow],
+    // entry i of a shard's list at [(parity*4 + class) * list_cap*kWfShards + shard*list_cap + i]:
     //   recA (o.xyz, exclude bits)   recB extension ray: (d.xyz, slot | kWfListAlsoExt if already resolved)
     //                                     shadow ray:    (light dir.xyz, t of the light's own primitive)
-    //   recC shadow rays only: (slot, light primitive index, its slot, -)
+    //   recC shadow rays only: (slot | kWfListAlsoExt if the slot also listed an extension ray, light primitive index, its slot, -)
+    // (the records ARE the ray lists: tail mode walks recB.w / recC.x of the previous iteration)
     float4 *recA, *recB;
     uint4 *recC;
+    uint32_t *dead;                  // [shard * list_cap + i]: slots that are dead after this iteration's shade launch (k_wf_gen's input)
+    uint32_t rearm;                  // k_wf_shade: list the dead slots (a k_wf_gen launch follows: some queue may hold work)
+    uint32_t gen_blocks;             // k_wf_gen: blocks per shard (block j of a shard takes chunks j, j + gen_blocks, ... of its dead list)
     float4 *staging[kWfRing];        // finished samples, per batch id (several batches can be in flight)
     uint32_t batch_id;           // id of the newest batch (k_wf_init: the batch being set up; k_wf_resolve / k_wf_finish: the batch to resolve / finish)
     WfStatus *status_out;            // k_wf_shade: where its first wave writes the PREVIOUS iteration's status record (pinned host memory), or null

@@ -187,7 +187,7 @@ struct ShadowOut { bool emit; f3 d; float t_l; uint32_t l_index, l_slot; };
 // without a walk to `radiance` or stores the NEE term and describes the shadow ray to trace.
 template <bool COUNT, bool FINISH>
 __device__ __forceinline__ ShadowOut light_sample(const WfParams &P, const LightRec &L, uint32_t slot, f3 pos, f3 nrm, uint32_t b_index,
-                                                  float u, float v2, f4 brdf, f4 beta, f4 &radiance, const uint32_t wl[4], ShadeCnt &cn)
+                                                  float u, float v2, f4 brdf, f4 beta, f4 &radiance, bool &rad_dirty, const uint32_t wl[4], ShadeCnt &cn)
 {
     const DevScene &S = P.sc;
     ShadowOut out{false, f3{0.0f, 0.0f, 0.0f}, 0.0f, 0u, 0u};
@@ -221,6 +221,7 @@ __device__ __forceinline__ ShadowOut light_sample(const WfParams &P, const Light
             if (COUNT) cn.hits++;
             const float qn = bits_f(0x7FC00000u);
             radiance = radiance + f4{qn, qn, qn, qn};
+            rad_dirty = true;
         }
     } else if (l_slot != kNoHit && cos_theta > 0.0f) {
         if (COUNT) cn.hits++;
@@ -237,11 +238,11 @@ __device__ __forceinline__ ShadowOut light_sample(const WfParams &P, const Light
     return out;
 }
 
-// (o, excl, d, resolved: the extension ray; sd, t_l, l_index, l_slot: the shadow ray -- what k_wf_shade copies into the
-// compacted ray records the traversal kernel streams; a shadow ray starts where the extension ray does)
+// What one shade step leaves behind: the path's registers (the slot's next state; the extension ray is R.ray_o / R.ray_d /
+// R.exclude) and the shadow ray, if one is emitted (it starts where the extension ray does).
 struct ShadeOut {
-    bool alive, emit_ext, ext_primary, emit_sh, sh_primary; uint32_t batch;
-    f3 o; uint32_t excl; f3 d; uint32_t resolved;
+    bool alive, emit_ext, emit_sh, sh_primary, rad_dirty; uint32_t batch;
+    PathRegs R;
     f3 sd; float t_l; uint32_t l_index, l_slot;
 };
 
@@ -256,7 +257,7 @@ struct ShadeOut {
 // One shade step of one path slot: steps 1-4 of k_wf_shade's description.  FINISH: the slot is
 // driven by k_wf_finish (no re-arming from the work queue; the caller traces the emitted rays itself).
 template <bool COUNT, bool FINISH>
-__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, uint32_t my_shard, ShadeCnt &cn, unsigned long long *tp = nullptr)
+__device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot, bool in_pool, ShadeCnt &cn, unsigned long long *tp = nullptr)
 {
     const DevScene &S = P.sc;
     PathRegs R;
@@ -277,8 +278,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
     bool alive = in_pool && (R.flags & kWfAlive);
     bool emit_ext = false, emit_sh = false;
-    bool ext_primary = false, sh_primary = false;     // ray classes: camera ray / shadow ray of a camera-ray hit
-    bool finished = false;
+    bool sh_primary = false;                          // ray class: shadow ray of a camera-ray hit
+    bool finished = false, rad_dirty = false;
     f3 out_sd = f3{0, 0, 0}; float out_tl = 0.0f; uint32_t out_lindex = 0, out_lslot = 0;   // the shadow ray, if one is emitted
     // the hit primitive's whole record, also in one batch (valid only for an alive slot with a hit)
     const uint32_t h_slot = f_bits(h.y);
@@ -291,7 +292,9 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         R.ray_o = xyz(v_ro); R.exclude = f_bits(v_ro.w);
         R.ray_d = xyz(v_rd);
         R.beta = f4{v_beta.x, v_beta.y, v_beta.z, v_beta.w};
-        R.radiance = f4{v_rad.x, v_rad.y, v_rad.z, v_rad.w};
+        // (a path's radiance is stored only once something has been added to it: until then the array holds what the
+        // slot's previous path left there)
+        R.radiance = (R.flags & kWfHasRad) ? f4{v_rad.x, v_rad.y, v_rad.z, v_rad.w} : f4{0.0f, 0.0f, 0.0f, 0.0f};
         R.rng = Rng{rs.x, rs.y, rs.z, rs.w};
         uint32_t wl[4];
         wavelengths_of((R.flags >> kWfLambdaShift) & 0x1FFu, wl);
@@ -299,7 +302,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
 
         // 1. the NEE term of the previous bounce, now that visibility is known (:187)
         if (R.flags & kWfShadow) {
-            if (vis_in == 1u) R.radiance = R.radiance + f4{v_nee.x, v_nee.y, v_nee.z, v_nee.w};
+            if (vis_in == 1u) { R.radiance = R.radiance + f4{v_nee.x, v_nee.y, v_nee.z, v_nee.w}; rad_dirty = true; }
             R.flags &= ~kWfShadow;
         }
         if (R.flags & kWfDying) {
@@ -358,8 +361,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
                         float v2 = rnd(R.rng);
                         // (one light: its records were fetched with scalar loads at the top; else per lane, here)
                         ShadowOut sh;
-                        if (S.nlight == 1u) sh = light_sample<COUNT, FINISH>(P, LU, slot, pos, nrm, b_index, u, v2, brdf, R.beta, R.radiance, wl, cn);
-                        else sh = light_sample<COUNT, FINISH>(P, load_light<false>(S, li), slot, pos, nrm, b_index, u, v2, brdf, R.beta, R.radiance, wl, cn);
+                        if (S.nlight == 1u) sh = light_sample<COUNT, FINISH>(P, LU, slot, pos, nrm, b_index, u, v2, brdf, R.beta, R.radiance, rad_dirty, wl, cn);
+                        else sh = light_sample<COUNT, FINISH>(P, load_light<false>(S, li), slot, pos, nrm, b_index, u, v2, brdf, R.beta, R.radiance, rad_dirty, wl, cn);
                         if (sh.emit) {
                             emit_sh = true;
                             sh_primary = depth == 0u;
@@ -432,117 +435,28 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     }
 
     CRT_PROBE(tp, 3)
-    if (!FINISH) {
-    // 3. re-arm dead slots with the next (sample, pixel) work item.  A queue's work range is split into kWfShards
-    //    contiguous sub-ranges with their own cursors, and several queues (batches) can be listed, oldest first.
-    //    Pass 0: the wave's OWN shard of every listed queue in turn, one atomic each -- the shards of a queue drain at
-    //    the same rate (every shard has the same number of waves), so at a batch boundary a wave simply goes on with
-    //    the next batch's queue instead of fighting for the last items of the old one (with small batches every
-    //    launch crosses a boundary: thousands of waves on the few cursors still open cost more than the launch).
-    //    Pass 1, only for lanes still empty: look at all cursors of a queue with one wave-wide load, take from a
-    //    non-empty shard, mark the queue done when there is none.
-    {
-        const bool want0 = in_pool && !alive;
-        bool want = want0;
-        const uint32_t lane = lane_id();
-        uint32_t si = 0;
-        int pass = 0, tries = 0;
-        for (int attempt = 0; attempt < 6 * (int)kWfRing; attempt++) {
-            const unsigned long long m = __ballot(want);
-            if (!m) break;
-            if (si >= P.seg_n) {
-                if (pass == 1) break;
-                pass = 1; si = 0; tries = 0;
-                continue;
-            }
-            const uint32_t sg = P.seg_order[si];
-            if (__hip_atomic_load(&P.wq[sg].work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { si++; tries = 0; continue; }
-            WfWorkQ *wq = P.wq + sg;
-            const uint32_t wps = P.seg[sg].work_per_shard;
-            const unsigned long long wtot = P.seg[sg].work_total;
-            const uint32_t sh_lane = lane % kWfShards;
-            const unsigned long long lo = (unsigned long long)sh_lane * wps;
-            const unsigned long long hi = min(lo + (unsigned long long)wps, wtot);
-            const uint32_t size_l = hi > lo ? (uint32_t)(hi - lo) : 0u;
-            uint32_t s_pick = my_shard;
-            if (pass == 0) {
-                // one uniform load of the own cursor: skip the atomic when this shard is already dry
-                const unsigned long long lo0 = (unsigned long long)my_shard * wps;
-                const unsigned long long hi0 = min(lo0 + (unsigned long long)wps, wtot);
-                const uint32_t cur0 = __hip_atomic_load(&wq->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                si++;                                                // (one attempt per queue in this pass)
-                if (hi0 <= lo0 || cur0 >= (uint32_t)(hi0 - lo0)) continue;
-            } else {
-                // look at every cursor at once (lane i loads shard i) and take from a shard that still holds work
-                const uint32_t cur_l = __hip_atomic_load(&wq->work[sh_lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long avail = __ballot(cur_l < size_l);
-                if (!avail) {                                        // every shard is exhausted
-                    if (lane == 0) __hip_atomic_store(&wq->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    si++; tries = 0;
-                    continue;
-                }
-                if (++tries > 2) { si++; tries = 0; }                // (at most two tries per queue; the slot retries next iteration)
-                const uint32_t rot = my_shard & 63u;
-                const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
-                s_pick = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
-            }
-            const uint32_t n = (uint32_t)__popcll(m);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&wq->work[s_pick].cur, n);
-            base = __shfl(base, 0, 64);
-            const uint32_t size_s = __shfl(size_l, (int)s_pick, 64);
-            const uint32_t got = base < size_s ? min(n, size_s - base) : 0u;
-            const uint32_t my = prefix_popc(m, lane);
-            if (want && my < got) {
-                want = false;
-                const unsigned long long w = (unsigned long long)s_pick * wps + base + my;
-                const uint32_t sample_off = (uint32_t)(w / P.npix_padded), pp = (uint32_t)(w % P.npix_padded);
-                const uint32_t tile = pp >> 6, l = pp & 63u;
-                const uint32_t lx = (tile % P.tiles_x) * 8u + (l & 7u), ly = (tile / P.tiles_x) * 8u + (l >> 3);
-                R.flags = 0;
-                if (lx < P.tw && ly < P.th) {
-                    const uint32_t px = P.x0 + lx, sample = P.seg[sg].first_sample + sample_off;
-                    const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
-                    R.rng = Rng{py, px * 100u, sample, P.tea[(size_t)ly * P.tw + lx]};       // :98 (tea(px, py*100) from k_wf_tea)
-                    float jx = rnd(R.rng);
-                    float fs = ((float)px + ((float)(sample % kGrid) + jx) / (float)kGrid) / (float)S.W;
-                    float jy = rnd(R.rng);
-                    float ft = ((float)S.H - (float)py + ((float)(sample % kGrid) + jy) / (float)kGrid) / (float)S.H;
-                    const f3 llc = f3{S.cam[0], S.cam[1], S.cam[2]}, hor = f3{S.cam[3], S.cam[4], S.cam[5]};
-                    const f3 ver = f3{S.cam[6], S.cam[7], S.cam[8]}, eye = f3{S.cam[9], S.cam[10], S.cam[11]};
-                    R.ray_o = eye;
-                    R.ray_d = normalize(((llc + hor * fs) + ver * ft) - eye);
-                    float ul = rnd(R.rng);
-                    uint32_t lambda = (uint32_t)(301.0f * ul);                                // :317-319
-                    R.beta = f4{1, 1, 1, 1}; R.radiance = f4{0, 0, 0, 0};
-                    R.last_pdf = 1.0f; R.etaScale = 1.0f; R.exclude = 0xFFFFFFFFu;
-                    R.work = (uint32_t)w;
-                    R.flags = kWfAlive | (lambda << kWfLambdaShift) | (sg << kWfBatchShift);
-                    alive = true;
-                    emit_ext = true;
-                    ext_primary = true;
-                    emit_sh = false;
-                    if (COUNT) { cn.rays++; cn.walk++; }
-                }
-                // (a work item outside a ragged tile is consumed without a path; the slot retries)
-                else want = true;
-            }
-        }
-        if (want0 && !alive) R.flags = 0;
-    }
+    if (!alive) R.flags = 0;
+    ShadeOut so;
+    so.alive = alive; so.emit_ext = emit_ext; so.emit_sh = emit_sh; so.sh_primary = sh_primary; so.rad_dirty = rad_dirty;
+    so.batch = (R.flags >> kWfBatchShift) & (kWfRing - 1u);
+    so.R = R; so.sd = out_sd; so.t_l = out_tl; so.l_index = out_lindex; so.l_slot = out_lslot;
+    return so;
+}
 
-    }
-
-    CRT_PROBE(tp, 4)
-    // 4. write the slot back
+// 4. write the slot back.  Returns 1 when the extension ray was resolved here (a non-finite ray, below).
+template <bool COUNT, bool FINISH>
+__device__ __forceinline__ uint32_t shade_store(const WfParams &P, uint32_t slot, bool in_pool, ShadeOut &so, ShadeCnt &cn)
+{
+    const DevScene &S = P.sc;
+    PathRegs &R = so.R;
     uint32_t resolved = 0u;
     if (in_pool) {
-        if (alive) {
+        if (so.alive) {
             stnt(&P.ray_o[slot], float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)});
             // A non-finite ray (e.g. refract at the numerical edge of total reflection) is decided
             // by the reference loop in its own order; do that here and flag the ray as resolved
             // so the traversal kernel stays free of the fallback.
-            if (emit_ext && (!finite3(R.ray_o) || !finite3(R.ray_d))) {
+            if (so.emit_ext && (!finite3(R.ray_o) || !finite3(R.ray_d))) {
                 P.hit[slot] = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, R.ray_o.x, R.ray_o.y, R.ray_o.z,
                                                 R.ray_d.x, R.ray_d.y, R.ray_d.z, R.exclude);
                 if (COUNT) cn.prims += S.nprim;
@@ -550,13 +464,15 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
             }
             stnt(&P.ray_d[slot], float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)});
             stnt(&P.beta[slot], float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w});
-            stnt(&P.radiance[slot], float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w});
+            if (so.rad_dirty || (FINISH && !(R.flags & kWfHasRad))) {   // (k_wf_finish re-reads it every step: stored once)
+                stnt(&P.radiance[slot], float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w});
+                R.flags |= kWfHasRad;
+            }
             stnt(&P.rng[slot], uint4{R.rng.x, R.rng.y, R.rng.z, R.rng.w});
         }
-        stnt(&P.misc[slot], uint4{R.work, alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)});
+        stnt(&P.misc[slot], uint4{R.work, so.alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)});
     }
-    return ShadeOut{alive, emit_ext, ext_primary, emit_sh, sh_primary, (R.flags >> kWfBatchShift) & (kWfRing - 1u),
-                    R.ray_o, R.exclude, R.ray_d, resolved, out_sd, out_tl, out_lindex, out_lslot};
+    return resolved;
 }
 
 // What the host's driver needs to know about iteration it_end - 1 of this pipe (lane i looks at shard i of
@@ -616,7 +532,7 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
     if (blockIdx.x == 0 && threadIdx.x < 64u && P.status_out != nullptr) write_status(P.ctl, P.wq, it, P.status_out);   // of the previous iteration
     if (blockIdx.x == 0 && threadIdx.x < kWfShards) {            // arm the next iteration's counters
         WfShard &nx = ctl->shard[(it + 1u) & 3u][threadIdx.x];   // (ring it-1 is still read in tail mode)
-        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0;
+        nx.n[0] = 0; nx.n[1] = 0; nx.n[2] = 0; nx.n[3] = 0; nx.cur = 0; nx.n_dead = 0;
         for (uint32_t b = 0; b < kWfRing; b++) nx.alive[b] = 0;
     }
     uint32_t slot, my_shard;
@@ -641,15 +557,18 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         slot = 0; in_pool = false;
         const uint32_t cls = j / P.tail_bound, e = j % P.tail_bound;
         if (cls < 4u && e < pv.n[cls]) {
-            const uint32_t entry = ldnt(&P.list[lbuf ^ 1u][cls][region + e]);
+            // (the records are the lists: an extension ray's slot is in recB.w -- its mark there means "resolved", the
+            // slot is still this thread's -- a shadow ray's in recC.x)
+            const size_t g = (size_t)((lbuf ^ 1u) * 4u + cls) * ((size_t)P.list_cap * kWfShards) + region + e;
+            const uint32_t entry = cls < 2u ? f_bits(ldnt(&P.recB[g]).w) : ldnt(&P.recC[g]).x;
             slot = entry & kWfListSlot;
-            in_pool = !(entry & kWfListAlsoExt);                 // else reached through its extension ray
+            in_pool = cls < 2u || !(entry & kWfListAlsoExt);     // else reached through its extension ray
         }
     }
     if (P.evict_mask) {
         // Move the (few) paths of the batches named by evict_mask out of the pool: their rays of the last
         // iteration are traced, so the slot state is complete; k_wf_finish continues them from the side pool.
-        // The slot is then dead and is re-armed below like any other.
+        // The slot is then dead and is listed for k_wf_gen below like any other.
         uint4 misc = uint4{0, 0, 0, 0};
         if (in_pool) misc = P.misc[slot];
         const uint32_t par = (misc.y >> kWfBatchShift) & (kWfRing - 1u);
@@ -681,20 +600,30 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
 #else
     unsigned long long *tp = nullptr;
 #endif
-    const ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, my_shard, cn, tp);
-    CRT_PROBE(tp, 5)
-    const bool emit_ext = so.emit_ext, ext_primary = so.ext_primary, emit_sh = so.emit_sh, sh_primary = so.sh_primary;
+    ShadeOut so = shade_body<COUNT, false>(P, slot, in_pool, cn, tp);
+    CRT_PROBE(tp, 4)
+    const bool emit_ext = so.emit_ext, emit_sh = so.emit_sh, sh_primary = so.sh_primary;
     {
         const uint32_t lane = lane_id();
-        // Four ray classes keep like with like in the traversal kernel: camera rays (coherent),
-        // bounce rays, shadow rays of camera-ray hits (coherent origins), other shadow rays.
-        const bool cl0 = emit_ext && ext_primary, cl1 = emit_ext && !ext_primary;
+        // Ray classes keep like with like in the traversal kernel: camera rays (class 0, listed by k_wf_gen),
+        // bounce rays, shadow rays of camera-ray hits (coherent origins), other shadow rays.  Dead slots go to
+        // the shard's dead list, from which k_wf_gen re-arms them by whole waves.
         const bool cl2 = emit_sh && sh_primary, cl3 = emit_sh && !sh_primary;
-        const unsigned long long m0 = __ballot(cl0), m1 = __ballot(cl1), m2 = __ballot(cl2), m3 = __ballot(cl3);
+        const bool dead = in_pool && !so.alive && P.rearm != 0u;
+        const unsigned long long m1 = __ballot(emit_ext), m2 = __ballot(cl2), m3 = __ballot(cl3), md = __ballot(dead);
         WfShard &sh = ctl->shard[ring][my_shard];
+        // The list positions first: the atomics' round trip runs under the write-back of the slot below.
+        uint32_t b1 = 0, b2 = 0, b3 = 0, bd = 0;
+        if (lane == 0) {
+            if (m1) b1 = atomicAdd(&sh.n[1], (uint32_t)__popcll(m1));
+            if (m2) b2 = atomicAdd(&sh.n[2], (uint32_t)__popcll(m2));
+            if (m3) b3 = atomicAdd(&sh.n[3], (uint32_t)__popcll(m3));
+            if (md) bd = atomicAdd(&sh.n_dead, (uint32_t)__popcll(md));
+        }
         if (P.count_alive) {
             // paths still in the pool, per batch id: the host retires a batch (eviction of its last paths, resolve)
-            // by these counts.  A wave holds paths of one to three batches as a rule: one ballot + atomic for each.
+            // by these counts (k_wf_gen adds the paths it starts).  A wave holds paths of one to three batches as a
+            // rule: one ballot + atomic for each.
             unsigned long long am = __ballot(so.alive);
             while (am) {
                 const uint32_t b = (uint32_t)__shfl((int)so.batch, __ffsll((long long)am) - 1, 64);
@@ -703,36 +632,28 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
                 am &= ~m;
             }
         }
-        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-        if (lane == 0) {
-            if (m0) b0 = atomicAdd(&sh.n[0], (uint32_t)__popcll(m0));
-            if (m1) b1 = atomicAdd(&sh.n[1], (uint32_t)__popcll(m1));
-            if (m2) b2 = atomicAdd(&sh.n[2], (uint32_t)__popcll(m2));
-            if (m3) b3 = atomicAdd(&sh.n[3], (uint32_t)__popcll(m3));
-        }
-        b0 = __shfl(b0, 0, 64); b1 = __shfl(b1, 0, 64); b2 = __shfl(b2, 0, 64); b3 = __shfl(b3, 0, 64);
+        const uint32_t resolved = shade_store<COUNT, false>(P, slot, in_pool, so, cn);
+        CRT_PROBE(tp, 5)
+        b1 = __shfl(b1, 0, 64); b2 = __shfl(b2, 0, 64); b3 = __shfl(b3, 0, 64); bd = __shfl(bd, 0, 64);
         const size_t region = (size_t)my_shard * P.list_cap;
-        // Next to every list entry goes the ray itself, as a compacted record at the same position: the traversal
-        // kernel streams rays in list order -- one coalesced round trip per refill instead of list entry -> slot ->
-        // ray_o / ray_d (-> light index -> its slot), three to four dependent ones through HBM-resident pool arrays.
+        // The rays as compacted records in list order: the traversal kernel streams them -- one coalesced round trip
+        // per refill instead of list entry -> slot -> ray_o / ray_d (-> light index -> its slot), three to four
+        // dependent ones through HBM-resident pool arrays.
         const size_t cls_stride = (size_t)P.list_cap * kWfShards;
+        const PathRegs &R = so.R;
         if (emit_ext) {
-            const uint32_t c = cl0 ? 0u : 1u;
-            const size_t e = region + (cl0 ? b0 + prefix_popc(m0, lane) : b1 + prefix_popc(m1, lane));
-            stnt(&P.list[lbuf][c][e], slot);
-            const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + e;
-            stnt(&P.recA[g], float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)});
-            stnt(&P.recB[g], float4{so.d.x, so.d.y, so.d.z, bits_f(slot | (so.resolved ? kWfListAlsoExt : 0u))});
+            const size_t g = (size_t)(lbuf * 4u + 1u) * cls_stride + region + b1 + prefix_popc(m1, lane);
+            stnt(&P.recA[g], float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)});
+            stnt(&P.recB[g], float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(slot | (resolved ? kWfListAlsoExt : 0u))});
         }
         if (emit_sh) {
             const uint32_t c = cl2 ? 2u : 3u;
-            const size_t e = region + (cl2 ? b2 + prefix_popc(m2, lane) : b3 + prefix_popc(m3, lane));
-            stnt(&P.list[lbuf][c][e], slot | (emit_ext ? kWfListAlsoExt : 0u));
-            const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + e;
-            stnt(&P.recA[g], float4{so.o.x, so.o.y, so.o.z, bits_f(so.excl)});
+            const size_t g = (size_t)(lbuf * 4u + c) * cls_stride + region + (cl2 ? b2 + prefix_popc(m2, lane) : b3 + prefix_popc(m3, lane));
+            stnt(&P.recA[g], float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)});
             stnt(&P.recB[g], float4{so.sd.x, so.sd.y, so.sd.z, so.t_l});
-            stnt(&P.recC[g], uint4{slot, so.l_index, so.l_slot, 0u});
+            stnt(&P.recC[g], uint4{slot | (emit_ext ? kWfListAlsoExt : 0u), so.l_index, so.l_slot, 0u});
         }
+        if (dead) stnt(&P.dead[region + bd + prefix_popc(md, lane)], slot);
     }
     if (COUNT) {
         wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_RAYS, cn.rays);
@@ -750,6 +671,159 @@ __global__ __launch_bounds__(CRT_WF_SHADE_BLOCK, CRT_WF_SHADE_MIN_WAVES) void k_
         atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 14, 1ull);
     }
 #endif
+}
+
+// ------------------------------------------------------------------ generate
+// Re-arm dead slots with the next (sample, pixel) work items -- by WHOLE WAVES: k_wf_shade lists the slots that are dead
+// after its launch (per shard, ballot-compacted), and here wave (shard, j) takes chunks j, j + gen_blocks, ... of 64 such
+// slots and, for each, 64 CONSECUTIVE work items = the 64 pixels of one 8x8 tile of one sample: one queue atomic per
+// wave, the sample / tile decode once per wave, a coalesced seed-table read, and every lane on the same code (inside the
+// shade kernel the same work ran with a fifth of the lanes on, after up to 6 x 32 attempts at the queues, with two
+// integer divisions per lane: a quarter of a shade wave's time).  A queue's work range is split into kWfShards sub-ranges
+// with their own cursors, all advanced in multiples of 64, and several queues (batches) can be listed, oldest first: a
+// wave takes the work for all of its chunks with ONE atomic from its OWN shard of the oldest listed queue that holds
+// some (the shards of a queue drain at the same rate, so at a batch boundary a wave simply goes on with the next
+// batch's queue), and looks at the other shards' cursors with one wave-wide load only when all of its own are dry.
+// Fewer than 64 dead slots at the end of a shard's list stay dead until the next launch lists them again.  The camera
+// rays are ray class 0 of the iteration's lists.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
+{
+    const DevScene &S = P.sc;
+    const uint32_t ring = it & 3u, lbuf = it & 1u;
+    WfCtl *ctl = P.ctl;
+    const uint32_t lane = lane_id();
+    const uint32_t my_shard = blockIdx.x % kWfShards, j = blockIdx.x / kWfShards;
+    WfShard &sh = ctl->shard[ring][my_shard];
+    const uint32_t n_chunks = min(sh.n_dead, P.list_cap) / 64u;          // (final: the shade launch is through)
+    if (j >= n_chunks) return;
+    const uint32_t mine = (n_chunks - j + P.gen_blocks - 1u) / P.gen_blocks;     // this wave's chunks: j, j + gen_blocks, ...
+    const size_t region = (size_t)my_shard * P.list_cap;
+    const size_t cls_stride = (size_t)P.list_cap * kWfShards;
+    // ---- the work for ALL of this wave's chunks in as few round trips as possible (the kernel sits between the shade
+    //      and the traversal launch of its pipe and is bound by dependent round trips, not by arithmetic): up to two
+    //      segments of consecutive work items -- the wave's own shard of the listed queues, oldest first, or one other
+    //      shard when all of its own are dry.  (Ranges, totals and steps are multiples of 64.)  What finds no work stays dead.
+    uint32_t seg_q[2] = {0, 0}, seg_n[2] = {0, 0}, nseg = 0, want = mine;
+    unsigned long long seg_w[2] = {0, 0};
+    for (uint32_t si = 0; si < P.seg_n && want > 0u && nseg < 2u; si++) {
+        const uint32_t sg = P.seg_order[si];
+        WfWorkQ *wq = P.wq + sg;
+        const uint32_t wps = P.seg[sg].work_per_shard;
+        const unsigned long long wtot = P.seg[sg].work_total, lo = (unsigned long long)my_shard * wps;
+        const uint32_t size = lo < wtot ? (uint32_t)min((unsigned long long)wps, wtot - lo) : 0u;
+        // (one uniform load of the cursor: no atomic on a shard that is already dry)
+        if (__hip_atomic_load(&wq->work[my_shard].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&wq->work[my_shard].cur, want * 64u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= size) continue;
+        const uint32_t got = min(want, (size - base) / 64u);
+        seg_q[nseg] = sg; seg_w[nseg] = lo + base; seg_n[nseg] = got; nseg++;
+        want -= got;
+    }
+    for (uint32_t si = 0; si < P.seg_n && nseg == 0u; si++) {            // every shard of every listed queue, one try each
+        const uint32_t sg = P.seg_order[si];
+        WfWorkQ *wq = P.wq + sg;
+        if (__hip_atomic_load(&wq->work_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;
+        const uint32_t wps = P.seg[sg].work_per_shard;
+        const unsigned long long wtot = P.seg[sg].work_total, lo_l = (unsigned long long)lane * wps;
+        const uint32_t size_l = lo_l < wtot ? (uint32_t)min((unsigned long long)wps, wtot - lo_l) : 0u;
+        const uint32_t cur_l = __hip_atomic_load(&wq->work[lane].cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long avail = __ballot(cur_l < size_l);
+        if (!avail) {                                                    // every shard is exhausted
+            if (lane == 0) __hip_atomic_store(&wq->work_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        const uint32_t rot = my_shard & 63u;
+        const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
+        const uint32_t s_pick = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&wq->work[s_pick].cur, want * 64u);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t size_s = (uint32_t)__shfl((int)size_l, (int)s_pick, 64);
+        if (base >= size_s) continue;
+        const uint32_t got = min(want, (size_s - base) / 64u);
+        seg_q[0] = sg; seg_w[0] = (unsigned long long)s_pick * wps + base; seg_n[0] = got; nseg = 1;
+        want -= got;
+    }
+    const uint32_t total = seg_n[0] + seg_n[1];
+    if (total == 0u) return;                                             // no work anywhere: the slots stay dead
+    // ---- list positions of the whole wave's camera rays: one atomic.  Every item of an 8x8 tile inside the frame
+    //      yields a path; an item outside a ragged tile is consumed without one (its slot stays dead).
+    const bool ragged = ((P.tw | P.th) & 7u) != 0u;
+    uint32_t n_valid[2] = {seg_n[0] * 64u, seg_n[1] * 64u};
+    if (ragged) {
+        for (uint32_t g = 0; g < 2u; g++) {
+            n_valid[g] = 0;
+            for (uint32_t k = 0; k < seg_n[g]; k++) {
+                const uint32_t tile = (uint32_t)((seg_w[g] + 64ull * k) % P.npix_padded) >> 6;
+                const uint32_t lx = (tile % P.tiles_x) * 8u + (lane & 7u), ly = (tile / P.tiles_x) * 8u + (lane >> 3);
+                n_valid[g] += (uint32_t)__popcll(__ballot(lx < P.tw && ly < P.th));
+            }
+        }
+    }
+    uint32_t b0 = 0;
+    if (lane == 0) {
+        b0 = atomicAdd(&sh.n[0], n_valid[0] + n_valid[1]);
+        if (P.count_alive) {
+            if (n_valid[0]) atomicAdd(&sh.alive[seg_q[0]], n_valid[0]);
+            if (n_valid[1]) atomicAdd(&sh.alive[seg_q[1]], n_valid[1]);
+        }
+    }
+    uint32_t c_rays = 0, pos = 0;                                        // pos: camera rays of this wave listed so far
+    bool have_b0 = false;
+    for (uint32_t k = 0; k < total; k++) {
+        const uint32_t g = k < seg_n[0] ? 0u : 1u, kk = g ? k - seg_n[0] : k;
+        const uint32_t sg = seg_q[g];
+        const unsigned long long w0 = seg_w[g] + 64ull * kk;
+        const uint32_t sample_off = (uint32_t)(w0 / P.npix_padded), pp0 = (uint32_t)(w0 % P.npix_padded);
+        const uint32_t tile = pp0 >> 6;
+        const uint32_t lx = (tile % P.tiles_x) * 8u + (lane & 7u), ly = (tile / P.tiles_x) * 8u + (lane >> 3);
+        const bool valid = lx < P.tw && ly < P.th;
+        const unsigned long long mv = __ballot(valid);
+        const uint32_t slot = ldnt(&P.dead[region + (size_t)(j + k * P.gen_blocks) * 64u + lane]);
+        f3 eye = f3{0.0f, 0.0f, 0.0f}, d = eye;
+        uint32_t resolved = 0u;
+        if (valid) {
+            const uint32_t px = P.x0 + lx, sample = P.seg[sg].first_sample + sample_off;
+            const uint32_t py = P.y0 + (ly / P.band) * P.band * P.stride + P.phase * P.band + ly % P.band;
+            Rng rng = Rng{py, px * 100u, sample, P.tea[(size_t)ly * P.tw + lx]};             // :98 (tea(px, py*100) from k_wf_tea)
+            const float jx = rnd(rng);
+            const float fs = ((float)px + ((float)(sample % kGrid) + jx) / (float)kGrid) / (float)S.W;
+            const float jy = rnd(rng);
+            const float ft = ((float)S.H - (float)py + ((float)(sample % kGrid) + jy) / (float)kGrid) / (float)S.H;
+            const f3 llc = f3{S.cam[0], S.cam[1], S.cam[2]}, hor = f3{S.cam[3], S.cam[4], S.cam[5]};
+            const f3 ver = f3{S.cam[6], S.cam[7], S.cam[8]};
+            eye = f3{S.cam[9], S.cam[10], S.cam[11]};
+            d = normalize(((llc + hor * fs) + ver * ft) - eye);
+            const float ul = rnd(rng);
+            const uint32_t lambda = (uint32_t)(301.0f * ul);                                  // :317-319
+            const uint32_t flags = kWfAlive | (lambda << kWfLambdaShift) | (sg << kWfBatchShift);
+            stnt(&P.ray_o[slot], float4{eye.x, eye.y, eye.z, bits_f(0xFFFFFFFFu)});
+            stnt(&P.ray_d[slot], float4{d.x, d.y, d.z, bits_f(0u)});
+            stnt(&P.beta[slot], float4{1.0f, 1.0f, 1.0f, 1.0f});
+            stnt(&P.rng[slot], uint4{rng.x, rng.y, rng.z, rng.w});
+            stnt(&P.misc[slot], uint4{(uint32_t)w0 + lane, flags, f_bits(1.0f), f_bits(1.0f)});   // work, flags, last_pdf, etaScale
+            // (a camera ray is finite by construction unless the camera itself is not: then it is resolved like any other)
+            if (!finite3(eye) || !finite3(d)) {
+                P.hit[slot] = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, eye.x, eye.y, eye.z, d.x, d.y, d.z, 0xFFFFFFFFu);
+                resolved = 1u;
+            }
+        }
+        if (!have_b0) { b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); have_b0 = true; }   // (its round trip ran under the first set-up)
+        if (valid) {
+            const size_t e = (size_t)(lbuf * 4u) * cls_stride + region + b0 + pos + prefix_popc(mv, lane);
+            stnt(&P.recA[e], float4{eye.x, eye.y, eye.z, bits_f(0xFFFFFFFFu)});
+            stnt(&P.recB[e], float4{d.x, d.y, d.z, bits_f(slot | (resolved ? kWfListAlsoExt : 0u))});
+            if (COUNT) c_rays++;
+        }
+        pos += (uint32_t)__popcll(mv);
+    }
+    if (COUNT) {
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_RAYS, c_rays);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_WALKED, c_rays);
+    }
 }
 
 // ------------------------------------------------------------------ trace
@@ -899,7 +973,7 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
                     d = xyz(rd);
                     active = true;
                     if (shadow) {
-                        slot = rc.x; t_max = rd.w;
+                        slot = rc.x & kWfListSlot; t_max = rd.w;    // (the mark: the slot also listed an extension ray -- tail mode's business)
                         b_index = rc.y;                           // the light's primitive index and slot
                         b_slot = rc.z;
                     } else {
@@ -1174,11 +1248,13 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFini
     const uint32_t seg = blockIdx.x / G.blocks_per_seg, blk = blockIdx.x % G.blocks_per_seg;
     WfCtl *ctl = G.ctl[seg];
     int *stk = lds_stack + lane_id();
-    const uint32_t my_shard = 0;
     // P.tail_bound = paths per wave: a wave runs until its longest path ends and every bounce costs the
     // slowest lane's walk, so when the GPU has nothing else to do few paths per wave finish sooner
     const uint32_t j = blk * P.tail_bound + threadIdx.x;
     const uint32_t count = min(ctl->side_count[G.batch[seg]], kWfSideCap);
+    // (the host sizes the grid by the most paths a pipe reported for the batch; paths beyond it would never be
+    // finished and resolve would read a stale staging cell: reported, and the host turns it into CRT_EDEVICE)
+    if (blk == 0 && threadIdx.x == 0 && count > G.blocks_per_seg * P.tail_bound) atomicAdd(&ctl->dropped, count - G.blocks_per_seg * P.tail_bound);
     const bool mine = threadIdx.x < P.tail_bound && j < count;
     const uint32_t slot = G.base[seg] + (mine ? j : 0u);
     uint32_t flags = 0;
@@ -1215,7 +1291,9 @@ __global__ __launch_bounds__(64) void k_wf_finish(const WfParams P, const WfFini
                     P.hit[slot] = float2{t_max, bits_f(b_slot)};
                 }
             }
-            const ShadeOut so = shade_body<COUNT, true>(P, slot, true, my_shard, cn);
+            ShadeOut so = shade_body<COUNT, true>(P, slot, true, cn);
+            const uint32_t resolved = shade_store<COUNT, true>(P, slot, true, so, cn);
+            (void)resolved;                                              // (read back from ray_d.w above)
             alive = so.alive; pend_ext = so.emit_ext; pend_sh = so.emit_sh;
         }
     }
@@ -1273,7 +1351,7 @@ __global__ void k_wf_init(const WfParams P)
         if (!P.keep_pool)
             for (int r = 0; r < 4; r++) {
                 for (int k = 0; k < 4; k++) c->shard[r][i].n[k] = 0;
-                c->shard[r][i].cur = 0;
+                c->shard[r][i].cur = 0; c->shard[r][i].n_dead = 0;
                 for (uint32_t b = 0; b < kWfRing; b++) c->shard[r][i].alive[b] = 0;
             }
         if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else { for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; c->dropped = 0; } }
@@ -1309,6 +1387,15 @@ hipError_t wf_launch_shade(const WfParams &P, uint32_t it, hipStream_t s)
     const dim3 gs(P.tail_bound ? kWfShards * bps : (P.P + CRT_WF_SHADE_BLOCK - 1) / CRT_WF_SHADE_BLOCK), bs(CRT_WF_SHADE_BLOCK);
     if (P.count) hipLaunchKernelGGL((k_wf_shade<true>), gs, bs, 0, s, P, it);
     else hipLaunchKernelGGL((k_wf_shade<false>), gs, bs, 0, s, P, it);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_gen(const WfParams &P, uint32_t it, hipStream_t s)
+{
+    if (P.gen_blocks == 0u) return hipErrorInvalidValue;
+    const dim3 gs(kWfShards * P.gen_blocks), bs(64);
+    if (P.count) hipLaunchKernelGGL((k_wf_gen<true>), gs, bs, 0, s, P, it);
+    else hipLaunchKernelGGL((k_wf_gen<false>), gs, bs, 0, s, P, it);
     return hipGetLastError();
 }
 

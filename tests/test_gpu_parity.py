@@ -484,7 +484,56 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             assert renderer.sample == total
     finally:
         for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 1, "wf_feed_pct": 100, "wf_finish_at": 32768, "wf_ahead": 3,
-                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 4, "wf_cohort": 16}.items():
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 8, "wf_cohort": 16}.items():
+            renderer.set_option(k, v)
+
+
+def test_staging_is_never_reallocated_under_a_live_pool(renderer, orc):
+    """Regression (round-2 advisor, high): a large batch after small ones kept the pool live when staging buffer 0
+    was large enough, and grew the OTHER ring buffers under the batches in flight.  Here: a large batch with a ring
+    of 2 (buffers 0-1 large), small batches with a ring of 32 (buffers 2-31 small), then a large batch and more small
+    ones without a sync in between.  The frame is the oracle's."""
+    from computeraytracer_amd import cornell
+    ps = cornell(256, 256)
+    sc = orc.Scene.from_packed(ps)
+    try:
+        renderer.upload(ps).build_accel("bvh2")
+        renderer.set_option("wf_pool", 1 << 18).set_option("wf_cohort", 1).set_option("wf_ring", 2)
+        renderer.frame(24).sync()
+        renderer.set_option("wf_ring", 32)
+        total = 24
+        for n in (1, 1, 1, 1, 1, 1, 24, 1, 1, 24, 2):     # (no sync: the pool stays live across the size changes)
+            renderer.frame(n)
+            total += n
+        renderer.sync()
+        assert renderer.sample == total
+        assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *sc.render(total)[:2])
+    finally:
+        renderer.set_option("wf_pool", 0).set_option("wf_cohort", 16).set_option("wf_ring", 32)
+
+
+def test_driver_rings_wrap_many_times(renderer, orc):
+    """One long run of the driver (round-2 verdict, item 6): 1 spp per call, every call its own batch, four pipes,
+    no sync -- 420 calls wrap the ring of batch ids (32), the status ring of every pipe (64 records) and the event
+    rings behind them several times, with up to 20 batches in flight in a pool that holds 20 calls' worth of paths
+    (publish, pump, evict, finish and resolve all run under back-pressure).  Bit-identical to the oracle at the end,
+    and a bound output is a complete frame whenever it is looked at."""
+    from computeraytracer_amd import cornell
+    W = H = 160
+    ps = cornell(W, H)
+    sc = orc.Scene.from_packed(ps)
+    try:
+        renderer.upload(ps).build_accel("bvh2")
+        for k, v in {"wf_pool": 1 << 19, "wf_pipes": 4, "wf_cohort": 1, "wf_ring": 32, "wf_finish_at": 2048}.items():
+            renderer.set_option(k, v)
+        calls = int(os.environ.get("CRT_TEST_LONG_CALLS", "420"))
+        for _ in range(calls):
+            renderer.frame(1)
+        renderer.sync()
+        assert renderer.sample == calls
+        assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *sc.render(calls)[:2])
+    finally:
+        for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_cohort": 16, "wf_ring": 32, "wf_finish_at": 32768}.items():
             renderer.set_option(k, v)
 
 
@@ -729,6 +778,26 @@ def test_out_of_memory_is_reported_and_the_context_recovers(orc):
     finally:
         r.set_option("debug_fail_alloc", 0)
         r.close()
+    # ... and while the acceleration structure is being built (either builder): the previous structure's arrays are
+    # gone by then, so the context must refuse to trace until a build has succeeded
+    for mode in ("bvh2", "lbvh"):
+        for k in (1, 2, 4):
+            r = Renderer(0)
+            try:
+                r.upload(ps).build_accel("bvh2").frame(1).sync()
+                r.reset()
+                r.set_option("debug_fail_alloc", k)
+                with pytest.raises(CrtError) as e:
+                    r.build_accel(mode)
+                assert e.value.code == -4, str(e.value)
+                r.set_option("debug_fail_alloc", 0)
+                with pytest.raises(CrtError, match="crt_build_accel first"):
+                    r.frame(1)
+                r.build_accel(mode).frame(2).sync()
+                assert_same_image(r.read_accum(), r.read_rgba8(), acc_o, rgba_o)
+            finally:
+                r.set_option("debug_fail_alloc", 0)
+                r.close()
 
 
 # ------------------------------------------------------------------ error behaviour
