@@ -373,11 +373,251 @@ static napi_value js_set_option(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+/* The display step without stopping the pipeline (include/crt.h): the newest complete frame + its sample index. */
+static napi_value js_read_latest_rgba8(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t t[4], smp = 0;
+    CRT_CHECK(env, ctx, "crt_tile", crt_tile(ctx, t));
+    size_t px = (size_t)t[2] * t[3];
+    void *data = NULL;
+    napi_value ab, ta, obj, sv;
+    NAPI_OK(env, napi_create_arraybuffer(env, px * 4, &data, &ab));
+    CRT_CHECK(env, ctx, "crt_read_latest_rgba8", crt_read_latest_rgba8(ctx, (uint8_t *)data, &smp));
+    NAPI_OK(env, napi_create_typedarray(env, napi_uint8_array, px * 4, ab, 0, &ta));
+    NAPI_OK(env, napi_create_object(env, &obj));
+    NAPI_OK(env, napi_create_uint32(env, smp, &sv));
+    NAPI_OK(env, napi_set_named_property(env, obj, "frame", ta));
+    NAPI_OK(env, napi_set_named_property(env, obj, "sample", sv));
+    return obj;
+}
+
+static napi_value js_latest_sample(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t s = 0;
+    CRT_CHECK(env, ctx, "crt_latest_sample", crt_latest_sample(ctx, &s));
+    napi_value out;
+    NAPI_OK(env, napi_create_uint32(env, s, &out));
+    return out;
+}
+
+static napi_value js_read_sample_rgba8(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t t[4], smp;
+    NAPI_OK(env, napi_get_value_uint32(env, argv[1], &smp));
+    CRT_CHECK(env, ctx, "crt_tile", crt_tile(ctx, t));
+    size_t px = (size_t)t[2] * t[3];
+    void *data = NULL;
+    napi_value ab, ta;
+    NAPI_OK(env, napi_create_arraybuffer(env, px * 4, &data, &ab));
+    CRT_CHECK(env, ctx, "crt_read_sample_rgba8", crt_read_sample_rgba8(ctx, smp, (uint8_t *)data));
+    NAPI_OK(env, napi_create_typedarray(env, napi_uint8_array, px * 4, ab, 0, &ta));
+    return ta;
+}
+
+/* ------------------------------------------------------------------ multi-GPU (include/crt.h "Multi-GPU") and composition
+ * The reference drives one GPUDevice (src/main.js:8-9); a Node host reaches the tile-partitioned configurations through
+ * these: one process (worker) per GPU, the communicator id made by one of them and passed around by the parent
+ * (host/multi.js). */
+static napi_value js_comm_unique_id(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    bool local = false;
+    NAPI_OK(env, napi_get_value_bool(env, argv[0], &local));
+    void *data = NULL;
+    napi_value ab;
+    NAPI_OK(env, napi_create_arraybuffer(env, CRT_COMM_ID_BYTES, &data, &ab));
+    int rc = crt_comm_unique_id(data, local ? CRT_COMM_LOCAL : CRT_COMM_RCCL);
+    if (rc != CRT_OK) return throw_crt(env, NULL, rc, "crt_comm_unique_id");
+    return ab;
+}
+
+static napi_value js_comm_init(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *p; size_t n;
+    int32_t rank, world;
+    if (!get_bytes(env, argv[1], &p, &n) || n != CRT_COMM_ID_BYTES) { napi_throw_type_error(env, NULL, "commInit: the id is the 128-byte buffer of commUniqueId"); return NULL; }
+    NAPI_OK(env, napi_get_value_int32(env, argv[2], &rank));
+    NAPI_OK(env, napi_get_value_int32(env, argv[3], &world));
+    CRT_CHECK(env, ctx, "crt_comm_init", crt_comm_init(ctx, p, rank, world));
+    return undefined(env);
+}
+
+static napi_value js_comm_partition(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t band;
+    NAPI_OK(env, napi_get_value_uint32(env, argv[1], &band));
+    CRT_CHECK(env, ctx, "crt_comm_partition", crt_comm_partition(ctx, band));
+    return undefined(env);
+}
+
+static napi_value js_comm_info(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int v[4];
+    CRT_CHECK(env, ctx, "crt_comm_info", crt_comm_info(ctx, v));
+    napi_value arr;
+    NAPI_OK(env, napi_create_array_with_length(env, 4, &arr));
+    for (uint32_t i = 0; i < 4; i++) {
+        napi_value e;
+        NAPI_OK(env, napi_create_int32(env, v[i], &e));
+        NAPI_OK(env, napi_set_element(env, arr, i, e));
+    }
+    return arr;
+}
+
+static napi_value js_comm_destroy(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    CRT_CHECK(env, ctx, "crt_comm_destroy", crt_comm_destroy(ctx));
+    return undefined(env);
+}
+
+static napi_value js_gather(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    int32_t what;
+    NAPI_OK(env, napi_get_value_int32(env, argv[1], &what));
+    CRT_CHECK(env, ctx, "crt_gather", crt_gather(ctx, what));
+    return undefined(env);
+}
+
+static napi_value read_frame(napi_env env, napi_callback_info info, int rgba)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t wh[2];
+    CRT_CHECK(env, ctx, "crt_image_size", crt_image_size(ctx, wh));
+    size_t px = (size_t)wh[0] * wh[1];
+    void *data = NULL;
+    napi_value ab, ta;
+    NAPI_OK(env, napi_create_arraybuffer(env, px * (rgba ? 4 : 16), &data, &ab));
+    if (rgba) CRT_CHECK(env, ctx, "crt_read_frame_rgba8", crt_read_frame_rgba8(ctx, (uint8_t *)data));
+    else CRT_CHECK(env, ctx, "crt_read_frame_accum", crt_read_frame_accum(ctx, (float *)data));
+    NAPI_OK(env, napi_create_typedarray(env, rgba ? napi_uint8_array : napi_float32_array, px * 4, ab, 0, &ta));
+    return ta;
+}
+static napi_value js_read_frame_rgba8(napi_env env, napi_callback_info info) { return read_frame(env, info, 1); }
+static napi_value js_read_frame_accum(napi_env env, napi_callback_info info) { return read_frame(env, info, 0); }
+
+static napi_value js_image_size(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t wh[2];
+    CRT_CHECK(env, ctx, "crt_image_size", crt_image_size(ctx, wh));
+    napi_value arr, a, b;
+    NAPI_OK(env, napi_create_array_with_length(env, 2, &arr));
+    NAPI_OK(env, napi_create_uint32(env, wh[0], &a));
+    NAPI_OK(env, napi_create_uint32(env, wh[1], &b));
+    NAPI_OK(env, napi_set_element(env, arr, 0, a));
+    NAPI_OK(env, napi_set_element(env, arr, 1, b));
+    return arr;
+}
+
+static napi_value js_set_row_bands(napi_env env, napi_callback_info info)
+{
+    ARGS(4)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t v[3];
+    for (int i = 0; i < 3; i++) NAPI_OK(env, napi_get_value_uint32(env, argv[i + 1], &v[i]));
+    CRT_CHECK(env, ctx, "crt_set_row_bands", crt_set_row_bands(ctx, v[0], v[1], v[2]));
+    return undefined(env);
+}
+
+/* Device addresses cross the boundary as BigInt (or a Number / null for "none"). */
+static int get_ptr(napi_env env, napi_value v, void **out)
+{
+    napi_valuetype t;
+    *out = NULL;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_null || t == napi_undefined) return 1;
+    if (t == napi_bigint) { uint64_t u; bool lossless; if (napi_get_value_bigint_uint64(env, v, &u, &lossless) != napi_ok) return 0; *out = (void *)(uintptr_t)u; return 1; }
+    if (t == napi_number) { int64_t i; if (napi_get_value_int64(env, v, &i) != napi_ok || i < 0) return 0; *out = (void *)(uintptr_t)i; return 1; }
+    return 0;
+}
+
+static napi_value ptr_pair(napi_env env, void *a, void *b)
+{
+    napi_value arr, x, y;
+    NAPI_OK(env, napi_create_array_with_length(env, 2, &arr));
+    NAPI_OK(env, napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)a, &x));
+    NAPI_OK(env, napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)b, &y));
+    NAPI_OK(env, napi_set_element(env, arr, 0, x));
+    NAPI_OK(env, napi_set_element(env, arr, 1, y));
+    return arr;
+}
+
+static napi_value js_device_buffers(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *a = NULL, *b = NULL;
+    CRT_CHECK(env, ctx, "crt_device_buffers", crt_device_buffers(ctx, &a, &b));
+    return ptr_pair(env, a, b);
+}
+
+static napi_value js_frame_device_buffers(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *a = NULL, *b = NULL;
+    CRT_CHECK(env, ctx, "crt_frame_device_buffers", crt_frame_device_buffers(ctx, &a, &b));
+    return ptr_pair(env, a, b);
+}
+
+static napi_value js_bind_output(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *a, *b;
+    if (!get_ptr(env, argv[1], &a) || !get_ptr(env, argv[2], &b)) { napi_throw_type_error(env, NULL, "bindOutput: device addresses are BigInt (or null)"); return NULL; }
+    CRT_CHECK(env, ctx, "crt_bind_output", crt_bind_output(ctx, a, b));
+    return undefined(env);
+}
+
+static napi_value js_set_stream(napi_env env, napi_callback_info info)
+{
+    ARGS(2)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    void *st;
+    if (!get_ptr(env, argv[1], &st)) { napi_throw_type_error(env, NULL, "setStream: a hipStream_t as BigInt (or null for the context's own)"); return NULL; }
+    CRT_CHECK(env, ctx, "crt_set_stream", crt_set_stream(ctx, st));
+    return undefined(env);
+}
+
 /* ------------------------------------------------------------------ asynchronous entry points
  * traceAsync(h, n), syncAsync(h), readRgba8Async(h), readAccumAsync(h) -> Promise.  The reference's frame() is
  * fire-and-forget (queue.submit, src/main.js:618-620): a Node display loop must not block its event loop on the
  * GPU either.  Jobs of one context run in call order. */
-enum { JOB_TRACE, JOB_SYNC, JOB_READ_RGBA8, JOB_READ_ACCUM };
+enum { JOB_TRACE, JOB_SYNC, JOB_READ_RGBA8, JOB_READ_ACCUM, JOB_GATHER, JOB_READ_FRAME_RGBA8, JOB_READ_FRAME_ACCUM, JOB_READ_SAMPLE_RGBA8 };
 typedef struct job {
     napi_async_work work;
     napi_deferred deferred;
@@ -399,7 +639,11 @@ static void job_execute(napi_env env, void *data)
     case JOB_TRACE: j->rc = crt_trace(ctx, j->n); break;
     case JOB_SYNC: j->rc = crt_sync(ctx); break;
     case JOB_READ_RGBA8: j->rc = crt_read_rgba8(ctx, (uint8_t *)j->data); break;
-    default: j->rc = crt_read_accum(ctx, (float *)j->data); break;
+    case JOB_READ_ACCUM: j->rc = crt_read_accum(ctx, (float *)j->data); break;
+    case JOB_GATHER: j->rc = crt_gather(ctx, (int)j->n); break;
+    case JOB_READ_FRAME_RGBA8: j->rc = crt_read_frame_rgba8(ctx, (uint8_t *)j->data); break;
+    case JOB_READ_SAMPLE_RGBA8: j->rc = crt_read_sample_rgba8(ctx, j->n, (uint8_t *)j->data); break;
+    default: j->rc = crt_read_frame_accum(ctx, (float *)j->data); break;
     }
     if (j->rc != CRT_OK) {
         const char *d = crt_last_error(ctx);
@@ -414,10 +658,11 @@ static void job_complete(napi_env env, napi_status status, void *data)
     napi_value result = NULL;
     if (status != napi_ok && j->rc == CRT_OK) { j->rc = CRT_EDEVICE; snprintf(j->err, sizeof j->err, "asynchronous call cancelled"); }
     if (j->rc == CRT_OK) {
-        if (j->op == JOB_READ_RGBA8 || j->op == JOB_READ_ACCUM) {
+        if (j->ab_ref) {
             napi_value ab;
+            const int bytes8 = j->op == JOB_READ_RGBA8 || j->op == JOB_READ_FRAME_RGBA8 || j->op == JOB_READ_SAMPLE_RGBA8;
             if (napi_get_reference_value(env, j->ab_ref, &ab) == napi_ok)
-                napi_create_typedarray(env, j->op == JOB_READ_RGBA8 ? napi_uint8_array : napi_float32_array, (size_t)j->px * 4, ab, 0, &result);
+                napi_create_typedarray(env, bytes8 ? napi_uint8_array : napi_float32_array, (size_t)j->px * 4, ab, 0, &result);
         }
         if (!result) napi_get_undefined(env, &result);
         napi_resolve_deferred(env, j->deferred, result);
@@ -444,20 +689,22 @@ static napi_value start_job(napi_env env, napi_callback_info info, int op)
     size_t argc = 2;
     napi_value argv[2];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    if (argc < (op == JOB_TRACE ? 2u : 1u)) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
+    if (argc < ((op == JOB_TRACE || op == JOB_GATHER || op == JOB_READ_SAMPLE_RGBA8) ? 2u : 1u)) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
     slot *sl = get_slot(env, argv[0]);
     if (!sl) return NULL;
     job *j = (job *)calloc(1, sizeof *j);
     j->sl = sl; j->op = op;
-    if (op == JOB_TRACE) {
-        if (napi_get_value_uint32(env, argv[1], &j->n) != napi_ok) { free(j); napi_throw_type_error(env, NULL, "traceAsync: sample count expected"); return NULL; }
+    if (op == JOB_TRACE || op == JOB_GATHER || op == JOB_READ_SAMPLE_RGBA8) {
+        if (napi_get_value_uint32(env, argv[1], &j->n) != napi_ok) { free(j); napi_throw_type_error(env, NULL, "traceAsync / gatherAsync: a number expected"); return NULL; }
     }
-    if (op == JOB_READ_RGBA8 || op == JOB_READ_ACCUM) {
+    if (op == JOB_READ_RGBA8 || op == JOB_READ_ACCUM || op == JOB_READ_FRAME_RGBA8 || op == JOB_READ_FRAME_ACCUM || op == JOB_READ_SAMPLE_RGBA8) {
+        const int frame = op == JOB_READ_FRAME_RGBA8 || op == JOB_READ_FRAME_ACCUM, bytes8 = op == JOB_READ_RGBA8 || op == JOB_READ_FRAME_RGBA8 || op == JOB_READ_SAMPLE_RGBA8;
         uint32_t t[4];
-        if (crt_tile(sl->ctx, t) != CRT_OK) { free(j); return throw_crt(env, sl->ctx, CRT_ESTATE, "crt_tile"); }
+        if (frame) { if (crt_image_size(sl->ctx, t + 2) != CRT_OK) { free(j); return throw_crt(env, sl->ctx, CRT_ESTATE, "crt_image_size"); } }
+        else if (crt_tile(sl->ctx, t) != CRT_OK) { free(j); return throw_crt(env, sl->ctx, CRT_ESTATE, "crt_tile"); }
         j->px = t[2] * t[3];
         napi_value ab;
-        if (napi_create_arraybuffer(env, (size_t)j->px * (op == JOB_READ_RGBA8 ? 4 : 16), &j->data, &ab) != napi_ok ||
+        if (napi_create_arraybuffer(env, (size_t)j->px * (bytes8 ? 4 : 16), &j->data, &ab) != napi_ok ||
             napi_create_reference(env, ab, 1, &j->ab_ref) != napi_ok) { free(j); napi_throw_error(env, NULL, "out of memory"); return NULL; }
     }
     napi_value promise, name;
@@ -487,6 +734,10 @@ static napi_value js_trace_async(napi_env env, napi_callback_info info) { return
 static napi_value js_sync_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_SYNC); }
 static napi_value js_read_rgba8_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_RGBA8); }
 static napi_value js_read_accum_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_ACCUM); }
+static napi_value js_gather_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_GATHER); }
+static napi_value js_read_sample_rgba8_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_SAMPLE_RGBA8); }
+static napi_value js_read_frame_rgba8_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_FRAME_RGBA8); }
+static napi_value js_read_frame_accum_async(napi_env env, napi_callback_info info) { return start_job(env, info, JOB_READ_FRAME_ACCUM); }
 
 static napi_value js_abi_version(napi_env env, napi_callback_info info)
 {
@@ -508,6 +759,14 @@ static napi_value init(napi_env env, napi_value exports)
         {"setOption", js_set_option}, {"abiVersion", js_abi_version},
         {"traceAsync", js_trace_async}, {"syncAsync", js_sync_async},
         {"readRgba8Async", js_read_rgba8_async}, {"readAccumAsync", js_read_accum_async},
+        {"readLatestRgba8", js_read_latest_rgba8}, {"latestSample", js_latest_sample}, {"readSampleRgba8", js_read_sample_rgba8},
+        {"readSampleRgba8Async", js_read_sample_rgba8_async},
+        {"commUniqueId", js_comm_unique_id}, {"commInit", js_comm_init}, {"commPartition", js_comm_partition},
+        {"commInfo", js_comm_info}, {"commDestroy", js_comm_destroy}, {"gather", js_gather},
+        {"readFrameRgba8", js_read_frame_rgba8}, {"readFrameAccum", js_read_frame_accum}, {"imageSize", js_image_size},
+        {"setRowBands", js_set_row_bands}, {"deviceBuffers", js_device_buffers}, {"frameDeviceBuffers", js_frame_device_buffers},
+        {"bindOutput", js_bind_output}, {"setStream", js_set_stream},
+        {"gatherAsync", js_gather_async}, {"readFrameRgba8Async", js_read_frame_rgba8_async}, {"readFrameAccumAsync", js_read_frame_accum_async},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -234,12 +234,26 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this exact workload (a bench run cannot profile
         # itself: rocprofv3 --pmc serialises the kernels): reported only while the kernel sources are the ones it was
         # measured on, null otherwise.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_all = None, None, None
+        trace_form = 2
+        for o in args.opt:
+            if o.startswith("wf_trace_form="):
+                trace_form = int(o.split("=")[1])
+        kernel_name = "k_wf_trace2" if (trace_form == 2 and st["bytes_per_box"] == 16 and st["width"] == 4) else "k_wf_trace"
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
-                tj = json.load(f)
-            if tj["workload"] == f"{args.scene} {W}x{H} {args.spp}spp n_gpus={world}" and tj.get("kernel_sources_sha256") == kernel_sources_sha256():
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], tj["source"]
+            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
+                entries = json.load(f)
+            key = f"{args.scene} {W}x{H} {args.spp}spp n_gpus={world} accel={args.accel}"
+            for tj in entries:
+                if tj["workload"] == key and tj.get("options", []) == args.opt and tj.get("kernel_sources_sha256") == kernel_sources_sha256():
+                    for kn, kv in tj["kernels"].items():
+                        if kn.startswith(kernel_name + "<false"):
+                            traffic = round(kv["traffic_bytes_per_launch"])
+                            traffic_src = f"profiles/r03_traffic.json ({tj['method']}; {kv['launches']} launches, L2 hit rate {kv['l2_hit_rate']:.3f})"
+                    # every kernel of the pass, per timed step is not known here (launch counts differ between the PMC
+                    # workload and this run): totals of the PMC workload itself
+                    traffic_all = {kn: {"bytes_per_launch": round(kv["traffic_bytes_per_launch"]), "l2_hit_rate": round(kv["l2_hit_rate"], 4)}
+                                   for kn, kv in tj["kernels"].items() if "<true" not in kn}
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -270,13 +284,15 @@ def main():
             "mrays_walked_per_s": round(walked / elapsed / 1e6, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_wf_trace", "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+                         "traffic_all_kernels": traffic_all,
+                         "measured_hbm_GBs_of_kernel": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None),
+                         "kernel": kernel_name, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": round(per_launch),
                          "bytes_per_ray": round(alg_bytes / max(m_rays, 1), 1),
                          "node_bytes_per_box": st["bytes_per_box"], "node_width": st["width"],
                          "boxes_per_ray": round(m_nodes / max(m_rays, 1), 2), "prims_per_ray": round(m_prims / max(m_rays, 1), 2),
                          "kernel_share_of_pass": round(kernel_ms / max(total_ms, 1e-9), 3),
-                         "note": "two half-pool pipes run on two streams, so two k_wf_trace launches (and a k_wf_shade) overlap: "
+                         "note": "two half-pool pipes run on two streams, so a traversal launch and the other pipe's k_wf_shade / k_wf_gen overlap: "
                                  "summed launch durations exceed the wall time of the pass; whole_pass_* = bytes / wall time",
                          "whole_pass_GBs": round(whole_pass, 1), "whole_pass_frac": round(whole_pass / HBM_PEAK_GBS, 5),
                          "accounting": "this build's records: 16 B per child box of a 64-byte quantised 4-wide node + 48 B per primitive "

@@ -35,6 +35,9 @@ SIGNATURES = {
     "crt_read_accum": (C.c_int, [_P, _P]),
     "crt_read_rgba8": (C.c_int, [_P, _P]),
     "crt_write_accum": (C.c_int, [_P, _P, C.c_uint32]),
+    "crt_read_latest_rgba8": (C.c_int, [_P, _P, _P]),
+    "crt_latest_sample": (C.c_int, [_P, _P]),
+    "crt_read_sample_rgba8": (C.c_int, [_P, C.c_uint32, _P]),
     "crt_device_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "crt_bind_output": (C.c_int, [_P, _P, _P]),
     "crt_set_stream": (C.c_int, [_P, _P]),
@@ -45,6 +48,19 @@ SIGNATURES = {
     "crt_last_kernel_ms": (C.c_int, [_P, _P, _P]),
     "crt_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "crt_accel_stats": (C.c_int, [_P, _P]),
+    "crt_get_device": (C.c_int, [_P, _P]),
+    "crt_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "crt_image_size": (C.c_int, [_P, _P]),
+    "crt_comm_unique_id": (C.c_int, [_P, C.c_int]),
+    "crt_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "crt_comm_partition": (C.c_int, [_P, C.c_uint32]),
+    "crt_gather": (C.c_int, [_P, C.c_int]),
+    "crt_read_frame_rgba8": (C.c_int, [_P, _P]),
+    "crt_read_frame_accum": (C.c_int, [_P, _P]),
+    "crt_frame_device_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "crt_comm_info": (C.c_int, [_P, _P]),
+    "crt_comm_destroy": (C.c_int, [_P]),
+    "crt_layout_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "crt_debug_intersect": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "crt_debug_probes": (C.c_int, [_P, _P]),
     "crt_debug_math": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t]),

@@ -128,6 +128,9 @@ struct crt_ctx {
     uint32_t band = 0x40000000u, stride = 1, phase = 0;   // row interleave (rectangular tile by default)
     DevBuf<float4> d_accum;
     DevBuf<uchar4> d_rgba;
+    DevBuf<uchar4> d_frames;        // option "frame_ring" = F: the rgba8 frame of each of the last F samples (tile-sized each)
+    uint32_t frame_ring = 0;
+    uint32_t resolved_upto = 0;     // samples whose resolve pass has been enqueued on the context's stream (frames <= this are in the ring / the framebuffer in stream order)
     float4 *accum_bound = nullptr;
     uchar4 *rgba_bound = nullptr;
     uint32_t sample = 0;            // samples requested so far (ComputeShader.wgsl:3 after that many frames)
@@ -146,7 +149,9 @@ struct crt_ctx {
     // wavefront pipeline (crt_wavefront.hip)
     int pipeline = 1;               // 1 = wavefront (default), 0 = v1 megakernel
     uint32_t wf_pool = 0;           // 0 = auto
-    uint32_t wf_waves_per_cu = 16;  // per pipe
+    uint32_t wf_waves_per_cu = 0;   // persistent traversal waves per CU and pipe; 0 = auto: 13 for k_wf_trace2, 16 for k_wf_trace (the
+                                    // regrouped form does more per wave and leaves the shade waves of the other pipe more of the SIMDs:
+                                    // profiles/r03_ab_waves.txt)
     int num_cu = 0;
     DevBuf<float4> w_ray_o, w_ray_d, w_sh_d, w_beta, w_radiance, w_nee, w_staging[kWfRing], w_recA, w_recB;
     DevBuf<uint4> w_rng, w_misc, w_recC;
@@ -157,6 +162,7 @@ struct crt_ctx {
     int wf_pipes = 2;
     int wf_defer = 1;               // 1: crt_trace returns with its batch in flight; its paths finish under the next batches (or at crt_sync)
     int wf_tail_walk = 1;           // shade walks the ray lists once few paths are left
+    int wf_trace_form = 2;          // traversal kernel: 2 = k_wf_trace2 (ray ring + primitive tasks), 1 = k_wf_trace
     int wf_chunk = 1;               // iterations per status record at most
     int wf_ahead = 3;               // iterations in flight per pipe before the pump waits for a status
     int wf_ring = 32;               // batches in flight at most (2..kWfRing): bounds how many calls a bound output can lag
@@ -222,6 +228,15 @@ int alloc_tile(crt_ctx *c)
     size_t n = (size_t)c->tw * c->th;
     HIPCHK(c, c->d_accum.alloc(n));
     HIPCHK(c, c->d_rgba.alloc(n));
+    if (c->frame_ring) HIPCHK(c, c->d_frames.alloc(n * c->frame_ring)); else c->d_frames.release();
+    return CRT_OK;
+}
+
+// (the frame ring alone: option "frame_ring" changes it without touching the accumulator)
+int alloc_frames(crt_ctx *c)
+{
+    const size_t n = (size_t)c->tw * c->th;
+    if (c->frame_ring) HIPCHK(c, c->d_frames.alloc(n * c->frame_ring)); else c->d_frames.release();
     return CRT_OK;
 }
 
@@ -232,7 +247,7 @@ int zero_state(crt_ctx *c)
         HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, n * sizeof(float4), c->stream));
         HIPCHK(c, hipMemsetAsync(rgba_ptr(c), 0, n * sizeof(uchar4), c->stream));
     }
-    c->sample = 0; c->published = 0; c->pending = 0;
+    c->sample = 0; c->published = 0; c->pending = 0; c->resolved_upto = 0;
     return CRT_OK;
 }
 
@@ -499,6 +514,8 @@ int upload_geometry(crt_ctx *c, int mode)
 // into a pinned host record by the first wave of the NEXT iteration's shade launch (write_status) and polled here.
 constexpr int kStatusRing = crt_ctx::kStatusSlots;
 
+uint32_t wf_waves(const crt_ctx *c) { return c->wf_waves_per_cu ? c->wf_waves_per_cu : (c->wf_trace_form == 2 && c->bvh4q.ok && !c->bvh8q.ok) ? 13u : 16u; }
+
 int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uint32_t ring)
 {
     if (c->w_dead.n < list_elems / 8) HIPCHK(c, c->w_dead.alloc(list_elems / 8));   // dead-slot lists: one list's worth per pipe
@@ -569,9 +586,9 @@ int wf_ensure(crt_ctx *c, size_t P, size_t staging_elems, size_t list_elems, uin
         HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    {   // deep-stack overflow area: 64 levels beyond the LDS part for every resident traversal lane
-        const size_t lanes = (size_t)c->num_cu * c->wf_waves_per_cu * 64u * (size_t)std::max(1, c->wf_pipes);
-        if (c->w_overflow.n < lanes * 64) HIPCHK(c, c->w_overflow.alloc(lanes * 64));
+    {   // deep-stack overflow area: kWfOverflowLevels levels beyond the LDS part for every resident traversal lane
+        const size_t lanes = (size_t)c->num_cu * wf_waves(c) * 64u * (size_t)std::max(1, c->wf_pipes);
+        if (c->w_overflow.n < lanes * kWfOverflowLevels) HIPCHK(c, c->w_overflow.alloc(lanes * kWfOverflowLevels));
     }
     return CRT_OK;
 }
@@ -678,7 +695,9 @@ int wf_resolve_batch(crt_ctx *c, const WfBatch &b)
     WfRun &r = *c->run;
     WfParams R = r.pipes[0].W;
     R.batch_id = b.id; R.n_samples = b.n;
+    R.frames = c->d_frames.p; R.frame_ring = c->frame_ring;
     HIPCHK(c, wf_launch_resolve(R, b.last_sample, c->stream));
+    c->resolved_upto = b.last_sample;
     HIPCHK(c, hipEventRecord(c->ev_resolved[b.id], c->stream));    // the id's queue, staging buffer and side pools are free after this
     r.resolved_recorded[b.id] = true;
     c->last_launches++;
@@ -1311,7 +1330,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
     if (rc) return rc;
     if (!r.live) {
         r.K = g.K; r.P = g.P; r.Pp = g.Pp; r.list_cap = g.list_cap;
-        r.trace_blocks = (uint32_t)c->num_cu * c->wf_waves_per_cu;
+        r.trace_blocks = (uint32_t)c->num_cu * wf_waves(c);
         r.open.clear();
         WfBatch nb;
         nb.n = n; nb.last_sample = c->published + n; nb.id = 0;
@@ -1360,8 +1379,9 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.accum = accum_ptr(c); W.rgba = rgba_ptr(c);
             W.tea = c->w_tea.p;
             W.count = c->counting ? 1u : 0u;
-            W.overflow_lanes = (uint32_t)c->num_cu * c->wf_waves_per_cu * 64u;
-            W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * 64u;
+            W.overflow_lanes = (uint32_t)c->num_cu * wf_waves(c) * 64u;
+            W.stack_overflow = c->w_overflow.p + (size_t)p * W.overflow_lanes * kWfOverflowLevels;
+            W.trace_form = (uint32_t)c->wf_trace_form;
             if (!c->pipe_stream[p]) {
                 // Streams beyond the hardware queues (4 by default) share one, and two pipes sharing a queue do not
                 // overlap at all (measured: 95 instead of 77 ms per S2 frame when the caller's framework had taken
@@ -1437,9 +1457,36 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
 
 }  // namespace
 
+extern "C" void crt_comm_on_destroy(crt_ctx *c);                 // crt_comm.cpp: the context's communicator goes with it
+
 extern "C" {
 
 int crt_abi_version(void) { return CRT_ABI_VERSION; }
+
+// (for crt_comm.cpp, which is written against the public ABI: an error with the context's message)
+int crt_internal_fail(crt_ctx *c, int code, const char *msg) { return fail(c, code, "%s", msg); }
+
+int crt_get_device(crt_ctx *c, int *out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    *out = c->device;
+    return CRT_OK;
+}
+
+int crt_get_stream(crt_ctx *c, void **out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    *out = (void *)c->stream;
+    return CRT_OK;
+}
+
+int crt_image_size(crt_ctx *c, uint32_t out[2])
+{
+    if (!c || !out) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_image_size: upload a scene first");
+    out[0] = c->W; out[1] = c->H;
+    return CRT_OK;
+}
 
 const char *crt_last_error(crt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1473,6 +1520,7 @@ int crt_create(crt_ctx **out, int device_ordinal)
 void crt_destroy(crt_ctx *c)
 {
     if (!c) return;
+    crt_comm_on_destroy(c);
     (void)hipSetDevice(c->device);
     // parked work is abandoned, but every stream must have drained before the buffers go
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1481,7 +1529,7 @@ void crt_destroy(crt_ctx *c)
     delete c->run;
     c->d_raw.release(); c->d_prim.release(); c->d_primD.release(); c->d_nodes.release(); c->d_nodes4.release(); c->d_nodes4q.release(); c->d_nodes8q.release(); c->d_lights.release(); c->w_overflow.release();
     c->d_slot_of_index.release(); c->d_spectra.release(); c->d_cie.release();
-    c->d_accum.release(); c->d_rgba.release(); c->d_counters.release();
+    c->d_accum.release(); c->d_rgba.release(); c->d_frames.release(); c->d_counters.release();
     c->w_ray_o.release(); c->w_ray_d.release(); c->w_sh_d.release(); c->w_beta.release(); c->w_radiance.release();
     c->w_nee.release(); for (uint32_t b = 0; b < kWfRing; b++) c->w_staging[b].release(); c->w_rng.release(); c->w_misc.release(); c->w_hit.release();
     c->w_vis.release(); c->w_dead.release(); c->w_recA.release(); c->w_recB.release(); c->w_recC.release(); c->w_tea.release(); c->w_wq.release();
@@ -1691,7 +1739,7 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
             P.first_sample = c->published + 1;                            // UpdateVariables.wgsl: sample++ first
             P.n_samples = n;
             HIPCHK(c, launch_trace(P, c->counting, c->accel_mode == CRT_ACCEL_NONE, c->stream));
-            c->published += n; c->sample += n;
+            c->published += n; c->sample += n; c->resolved_upto = c->published;
             left -= n;
             c->last_launches++;
         }
@@ -1747,6 +1795,68 @@ int crt_read_rgba8(crt_ctx *c, uint8_t *out)
     return wf_check_dropped(c);
 }
 
+// Drive the pipeline until the resolve pass of the batch that holds `sample` is on the context's stream.
+static int wf_wait_sample(crt_ctx *c, uint32_t sample)
+{
+    if (sample <= c->resolved_upto) return CRT_OK;
+    if (c->pipeline != 1 || c->accel_mode != CRT_ACCEL_BVH2) return wf_flush(c);
+    if (sample > c->published) { int rc = wf_publish_pending(c, true); if (rc) return rc; }   // (merged small calls wait for more: not any longer)
+    const double t_start = wf_now_ms();
+    for (int guard = 0; sample > c->resolved_upto; guard++) {
+        WfRun *r = c->run;
+        if (!r || !r->live || r->open.empty()) break;
+        // the newest batch is only retired by a flush (nothing comes behind it under which its tail could finish)
+        if (r->open.back().last_sample - r->open.back().n < sample) return wf_flush(c);
+        if ((guard & 15) == 15 && wf_now_ms() - t_start > kWfStallMs) return fail(c, CRT_EDEVICE, "wavefront driver: waiting for sample %u stalled (%s)", sample, wf_state(c).c_str());
+        int rc = wf_poll_all(c);
+        if (rc) return rc;
+        if (sample <= c->resolved_upto) break;
+        rc = wf_wait_progress(c);
+        if (rc) return rc;
+    }
+    return CRT_OK;
+}
+
+int crt_latest_sample(crt_ctx *c, uint32_t *out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    if (c->run && c->run->live) { HIPCHK(c, hipSetDevice(c->device)); int rc = wf_poll_all(c); if (rc) return rc; }   // (retire what has finished meanwhile)
+    *out = c->resolved_upto;
+    return CRT_OK;
+}
+
+int crt_read_latest_rgba8(crt_ctx *c, uint8_t *out, uint32_t *sample)
+{
+    if (!c || !out) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_latest_rgba8: no scene");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->run && c->run->live) { int rc = wf_poll_all(c); if (rc) return rc; }
+    // No flush: in stream order the framebuffer holds the complete frame of the newest batch whose resolve pass has been
+    // enqueued (crt_trace's contract for bound outputs); the copy is queued behind it.
+    const uint32_t s = c->resolved_upto;
+    const size_t n = (size_t)c->tw * c->th;
+    if (n) HIPCHK(c, hipMemcpyAsync(out, rgba_ptr(c), n * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sample) *sample = s;
+    return CRT_OK;
+}
+
+int crt_read_sample_rgba8(crt_ctx *c, uint32_t sample, uint8_t *out)
+{
+    if (!c || !out) return CRT_EINVAL;
+    if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: no scene");
+    if (!c->frame_ring || !c->d_frames.p) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: set option frame_ring first (frames kept per sample)");
+    if (sample == 0 || sample > c->sample) return fail(c, CRT_EINVAL, "crt_read_sample_rgba8: sample %u has not been requested (1..%u)", sample, c->sample);
+    if (c->sample - sample >= c->frame_ring) return fail(c, CRT_EINVAL, "crt_read_sample_rgba8: sample %u has left the ring of %u frames (%u requested)", sample, c->frame_ring, c->sample);
+    if (c->pipeline != 1 || c->accel_mode != CRT_ACCEL_BVH2) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: frames are kept by the wavefront pipeline only");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = wf_wait_sample(c, sample); if (rc) return rc; }
+    const size_t n = (size_t)c->tw * c->th;
+    if (n) HIPCHK(c, hipMemcpyAsync(out, c->d_frames.p + (size_t)((sample - 1u) % c->frame_ring) * n, n * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return wf_check_dropped(c);
+}
+
 int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
 {
     if (!c || !in) return CRT_EINVAL;
@@ -1756,7 +1866,7 @@ int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(accum_ptr(c), in, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->sample = sample; c->published = sample; c->pending = 0;
+    c->sample = sample; c->published = sample; c->pending = 0; c->resolved_upto = sample;
     return CRT_OK;
 }
 
@@ -1904,9 +2014,15 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_pool_spp")) { c->wf_pool_spp = (int)std::min<int64_t>(64, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_feed_pct")) { c->wf_feed = (double)std::min<int64_t>(400, std::max<int64_t>(10, value)) / 100.0; return CRT_OK; }
     if (!std::strcmp(name, "wf_tail_walk")) { c->wf_tail_walk = value != 0; return CRT_OK; }
+    if (!std::strcmp(name, "frame_ring")) {
+        c->frame_ring = (uint32_t)std::min<int64_t>(256, std::max<int64_t>(0, value));
+        if (c->have_scene) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return alloc_frames(c); }
+        return CRT_OK;
+    }
+    if (!std::strcmp(name, "wf_trace_form")) { c->wf_trace_form = value == 1 ? 1 : 2; return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }
-    if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(1, value)); return CRT_OK; }
+    if (!std::strcmp(name, "wf_waves_per_cu")) { c->wf_waves_per_cu = (uint32_t)std::min<int64_t>(32, std::max<int64_t>(0, value)); return CRT_OK; }
     if (!std::strcmp(name, "time_kernels")) {
         // value > 1 also creates the event pairs for that many launches now (event creation costs ~10 us apiece,
         // which would otherwise land in the region being timed)

@@ -91,6 +91,7 @@ constexpr uint32_t kWfRing = 32;                                // batch ids cyc
 // their end on another stream.  Side-pool slots precede the pool in the same arrays:
 // [(id*pipes + pipe)*kWfSideCap, +kWfSideCap).
 constexpr uint32_t kWfSideCap = 65536;
+constexpr uint32_t kWfOverflowLevels = 96;                   // global stack levels per traversal lane beyond the LDS entries
 
 // Every queue counter is sharded kWfShards ways, one 128-byte line per shard: same-address
 // returning atomics serialize at ~11 ns each on gfx950, which at one atomic per wave would
@@ -193,9 +194,12 @@ struct WfParams {
     uint32_t n_samples;              // k_wf_resolve: samples of the batch to resolve
     float4 *accum;
     uchar4 *rgba;
+    uchar4 *frames;                  // k_wf_resolve: ring of `frame_ring` tile-sized rgba8 frames, frame of sample s at [(s - 1) % frame_ring], or null
+    uint32_t frame_ring;
     const uint32_t *tea;             // per tile pixel: tea(px, py*100), the 16-round seed of the pixel's RNG (:98), computed once
     uint32_t count;                  // 1: maintain ctl->counters
-    int *stack_overflow;             // [level - kWfStack][global lane], for stacks deeper than the LDS part
+    uint32_t trace_form;             // 2: k_wf_trace2 (ray ring + primitive tasks) where the tree is the quantised 4-wide one; else k_wf_trace
+    int *stack_overflow;             // [level - LDS entries][global lane], for stacks deeper than the LDS part (kWfOverflowLevels levels)
     uint32_t overflow_lanes;
 };
 

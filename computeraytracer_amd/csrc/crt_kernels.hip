@@ -328,4 +328,33 @@ hipError_t launch_debug_math(int fn, const float *a, const float *b, float *out,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ frame assembly (crt_comm.cpp)
+// The gathered strips [world][rows_max][W] back into image rows [H][W]: row y of the frame belongs to part
+// (y / band) % world and is its local row (y / band / world) * band + y % band (band = 0: contiguous strips of
+// ceil(H / world) rows) -- the layout of crt_set_row_bands / crt_layout_rows.  One element = 16 B (accumulator) or 4 B (rgba8).
+template <typename T>
+__global__ __launch_bounds__(256) void k_assemble(const T *__restrict__ full, T *__restrict__ frame, uint32_t W, uint32_t H, uint32_t world,
+                                                  uint32_t rows_max, uint32_t band)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)W * H) return;
+    const uint32_t y = (uint32_t)(i / W), x = (uint32_t)(i % W);
+    uint32_t part, local;
+    if (band) { const uint32_t b = y / band; part = b % world; local = (b / world) * band + y % band; }
+    else { const uint32_t per = (H + world - 1u) / world; part = y / per; local = y % per; }
+    frame[i] = full[((size_t)part * rows_max + local) * W + x];
+}
+
+hipError_t launch_assemble(const void *full, void *frame, uint32_t elem_bytes, uint32_t W, uint32_t H, uint32_t world, uint32_t rows_max,
+                           uint32_t band, hipStream_t stream)
+{
+    const size_t n = (size_t)W * H;
+    if (n == 0) return hipSuccess;
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (elem_bytes == 16u) hipLaunchKernelGGL((k_assemble<float4>), g, b, 0, stream, (const float4 *)full, (float4 *)frame, W, H, world, rows_max, band);
+    else if (elem_bytes == 4u) hipLaunchKernelGGL((k_assemble<uint32_t>), g, b, 0, stream, (const uint32_t *)full, (uint32_t *)frame, W, H, world, rows_max, band);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace crt

@@ -227,7 +227,11 @@ __device__ __forceinline__ ShadowOut light_sample(const WfParams &P, const Light
         if (COUNT) cn.hits++;
         const f4 nee = nee_term(S, L, pos, ldir, t_l, cos_theta, sample_spectrum(S, f_bits(L.L0.w), wl));
         f4 c = (brdf * nee) * beta;          // added to radiance iff the light is visible
+#ifndef CRT_WHATIF_NO_NEE
         stnt(&P.nee[slot], float4{c.x, c.y, c.z, c.w});
+#else
+        if (c.x == 12345.678f) stnt(&P.nee[slot], float4{c.x, c.y, c.z, c.w});
+#endif
         if (FINISH) {                        // (k_wf_finish traces from the slot arrays; the pool's
             P.sh_d[slot] = float4{ldir.x, ldir.y, ldir.z, t_l};   //  traversal kernel from the ray records)
             P.vis[slot] = include;
@@ -272,7 +276,10 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     uint32_t vis_in = 0;
     if (in_pool) {
         misc = ldnt(&P.misc[slot]); v_ro = ldnt(&P.ray_o[slot]); v_rd = ldnt(&P.ray_d[slot]); v_beta = ldnt(&P.beta[slot]);
-        v_rad = ldnt(&P.radiance[slot]); rs = ldnt(&P.rng[slot]); h = ldnt(&P.hit[slot]); vis_in = ldnt(&P.vis[slot]); v_nee = ldnt(&P.nee[slot]);
+        v_rad = ldnt(&P.radiance[slot]); rs = ldnt(&P.rng[slot]); h = ldnt(&P.hit[slot]); vis_in = ldnt(&P.vis[slot]);
+#ifndef CRT_WHATIF_NO_NEE                 /* sensitivity probe (wrong image): the pass without the nee stream */
+        v_nee = ldnt(&P.nee[slot]);
+#endif
     }
     CRT_PROBE(tp, 1)
     R.work = misc.x; R.flags = misc.y; R.last_pdf = bits_f(misc.z); R.etaScale = bits_f(misc.w);
@@ -452,7 +459,9 @@ __device__ __forceinline__ uint32_t shade_store(const WfParams &P, uint32_t slot
     uint32_t resolved = 0u;
     if (in_pool) {
         if (so.alive) {
+#ifndef CRT_WHATIF_NO_RAYW           /* sensitivity probe (wrong image): the slot's ray arrays not written */
             stnt(&P.ray_o[slot], float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)});
+#endif
             // A non-finite ray (e.g. refract at the numerical edge of total reflection) is decided
             // by the reference loop in its own order; do that here and flag the ray as resolved
             // so the traversal kernel stays free of the fallback.
@@ -462,13 +471,18 @@ __device__ __forceinline__ uint32_t shade_store(const WfParams &P, uint32_t slot
                 if (COUNT) cn.prims += S.nprim;
                 resolved = 1u;
             }
+#ifndef CRT_WHATIF_NO_RAYW
             stnt(&P.ray_d[slot], float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)});
+#endif
             stnt(&P.beta[slot], float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w});
             if (so.rad_dirty || (FINISH && !(R.flags & kWfHasRad))) {   // (k_wf_finish re-reads it every step: stored once)
                 stnt(&P.radiance[slot], float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w});
                 R.flags |= kWfHasRad;
             }
             stnt(&P.rng[slot], uint4{R.rng.x, R.rng.y, R.rng.z, R.rng.w});
+#ifdef CRT_WHATIF_EXTRA_STREAM          /* sensitivity probe: 16 B more read and written per live slot (an array the pool does not use) */
+            if (!FINISH) { const float4 x = ldnt(&P.sh_d[slot]); stnt(&P.sh_d[slot], float4{x.y, x.x, x.w, x.z}); }
+#endif
         }
         stnt(&P.misc[slot], uint4{R.work, so.alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)});
     }
@@ -1231,6 +1245,357 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
     }
 }
 
+// ------------------------------------------------------------------ trace, second form
+// The same walk with the lanes regrouped by what they do next (round-2 verdict, item 1):
+//  * RAY RING.  A chunk of up to 64 rays is fetched and SET UP by the whole wave at once (record loads, the three
+//    reciprocals, the folded plane constants: every lane on the same code) into a ring of ready-to-run rays in LDS, and
+//    idle lanes pick rays up from it whenever CRT_WF_PICK_AT of them are idle: a pick-up is four DS reads, so it can
+//    run at a granularity at which the first form's refill (global loads + set-up under a quarter-filled mask) could
+//    not -- the inner-node passes no longer carry a dozen finished lanes on average.
+//  * PRIMITIVE TASKS.  A leaf pass does not loop over each lane's own leaf (lanes with one triangle idling behind the
+//    lane with four): the waiting leaves are expanded into (ray, primitive) tasks in LDS, compacted over the wave with
+//    bit-plane prefix counts, and lane k runs task k -- the ray comes over from its owner's registers (ds_bpermute),
+//    the result goes back through an LDS cell per ray, `min` over the 64-bit key (t bits, 0xFFFFFFFE - index): the
+//    order-independent form of the reference's rule "closest t, equal t -> later primitive" (:557,:609), so any number
+//    of tasks of one ray may run side by side.  One pass = at most 64 tasks, started once CRT_WF_LEAF2_AT lanes hold a leaf.
+// Stack: 16 entries per lane in LDS, the rest in the global overflow area.  LDS: 4 + 2.25 + 1 KB per wave.
+#ifndef CRT_WF_PICK_AT
+#define CRT_WF_PICK_AT 8
+#endif
+#ifndef CRT_WF_LEAF2_AT
+#define CRT_WF_LEAF2_AT 32
+#endif
+#ifndef CRT_WF_STALL_AT
+#define CRT_WF_STALL_AT 24
+#endif
+constexpr int kStk2 = 16;
+#ifndef CRT_WF_RING
+#define CRT_WF_RING 32
+#endif
+constexpr uint32_t kRing2 = CRT_WF_RING;        // ready rays per refill of the ring (LDS: 7.3 KB per wave with 32, so that a few waves of the
+                                                // other pipe's traversal launch fit beside sixteen of this one and the two launches' tail and ramp-up overlap)
+
+__device__ __forceinline__ int stack_pop2(const int *stk, const int *ovf, size_t ovl, int sp)
+{
+    int v = stk[(sp < kStk2 ? sp : kStk2 - 1) * 64];
+    if (sp >= kStk2) v = *(const volatile int *)(ovf + (size_t)(sp - kStk2) * ovl);   // (volatile: keeps it apart from the DS read)
+    return v;
+}
+// lanes below this one whose bit is set in m
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// (t, index) of a hit as one ordered key: smaller = better under the reference's rule; index none -> low word all ones
+__device__ __forceinline__ unsigned long long hit_key(float t, uint32_t index)
+{
+    return ((unsigned long long)f_bits(t) << 32) | (unsigned long long)(index == kNoHit ? 0xFFFFFFFFu : 0xFFFFFFFEu - index);
+}
+
+#ifndef CRT_WF_T2_WAVES
+#define CRT_WF_T2_WAVES 5
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParams P, uint32_t it)
+{
+    __shared__ int lds_stack[kStk2 * 64];
+    __shared__ float4 ring[4][kRing2];           // ready rays: (o, exclude) (d, slot | shadow << 31) (id', t_max) (oid', -)
+    __shared__ uint2 ring_l[kRing2];             //             (b_index, b_slot): the light's primitive for a shadow ray
+    __shared__ unsigned long long cell[64];      // per lane: hit_key of its ray's best hit so far
+    __shared__ uint32_t cslot[64];               // ... and that primitive's slot
+    __shared__ uint32_t tasks[64];               // owner lane | (primitive of its leaf) << 6
+    WfCtl *ctl = P.ctl;
+    const uint4 *__restrict__ nodesq = P.sc.nodes4q;
+    const f3 qscale = f3{P.sc.qscale[0], P.sc.qscale[1], P.sc.qscale[2]}, qbase = f3{P.sc.qbase[0], P.sc.qbase[1], P.sc.qbase[2]};
+    const float4 *__restrict__ prim = P.sc.prim;
+    const float4 *__restrict__ primD = P.sc.primD;
+    uint32_t *__restrict__ g_vis = P.vis;
+    float2 *__restrict__ g_hit = P.hit;
+    const size_t cls_stride = (size_t)P.list_cap * kWfShards;
+    const float4 *__restrict__ recA = P.recA + (size_t)((it & 1u) * 4u) * cls_stride;
+    const float4 *__restrict__ recB = P.recB + (size_t)((it & 1u) * 4u) * cls_stride;
+    const uint4 *__restrict__ recC = P.recC + (size_t)((it & 1u) * 4u) * cls_stride;
+    const float hit_pad = P.sc.hit_pad;
+    const int root = P.sc.root4;
+    int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
+    const size_t ovl = P.overflow_lanes;
+    const uint32_t nprim = P.sc.nprim;
+    DevScene S = P.sc;                                         // for the rare patch / sphere tests
+    S.prim = prim; S.primD = primD;
+
+    const uint32_t ringi = it & 3u;
+    const uint32_t lane = lane_id();
+    int *stk = lds_stack + lane;
+    const float t_min = 0.001f;
+
+    // wave-uniform fetch state: current shard, its class end offsets, the reserved chunk [pos,end), the ring [head, head+n)
+    uint32_t cur_shard = blockIdx.x % kWfShards, sh_e0 = 0, sh_e1 = 0, sh_e2 = 0, sh_total = 0;
+    uint32_t chunk_pos = 0, chunk_end = 0, ring_head = 0, ring_n = 0;
+    bool have_shard = false, exhausted = false;
+    {
+        const WfShard &so = ctl->shard[ringi][cur_shard];
+        sh_e0 = so.n[0]; sh_e1 = sh_e0 + so.n[1]; sh_e2 = sh_e1 + so.n[2]; sh_total = sh_e2 + so.n[3];
+        have_shard = sh_total > 0u;
+    }
+    bool active = false;
+    int pend = 0;                                   // a leaf put aside, 0 = none
+    f3 o = f3{0, 0, 0}, d = f3{0, 0, 0}, id = f3{0, 0, 0}, oid = f3{0, 0, 0};
+    uint32_t excl = 0, slot = 0, b_index = kNoHit, b_slot = kNoHit, b_slot_in = kNoHit;
+    float t_max = 0.0f;
+    bool shadow = false;
+    int node = kNoNode, sp = 0;
+    bool gx = false, gy = false, gz = false;         // the hi plane is the near one on that axis
+    uint32_t c_nodes = 0, c_prims = 0;
+    uint32_t d_inner_it = 0, d_inner_act = 0, d_leaf_it = 0, d_leaf_act = 0, d_prim_it = 0, d_refill = 0, d_refill_lanes = 0, d_scans = 0;   // lane 0 only
+
+    for (;;) {
+        // ---- idle lanes pick ready rays up from the ring; an empty ring is refilled with the next chunk first
+        const unsigned long long idle = __ballot(!active);
+        const int nidle = __popcll(idle);
+        if (nidle >= CRT_WF_PICK_AT) {
+            if (ring_n == 0u && !exhausted) {
+                for (int guard = 0; chunk_pos == chunk_end && !exhausted && guard < 2 * (int)kWfShards; guard++) {
+                    if (have_shard) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&ctl->shard[ringi][cur_shard].cur, (uint32_t)kTraceChunk);
+                        base = __shfl(base, 0, 64);
+                        if (base < sh_total) { chunk_pos = base; chunk_end = min(base + (uint32_t)kTraceChunk, sh_total); break; }
+                        have_shard = false;
+                    }
+                    if (COUNT) d_scans++;
+                    const WfShard &sl = ctl->shard[ringi][lane % kWfShards];
+                    const uint32_t e0 = sl.n[0], e1 = e0 + sl.n[1], e2 = e1 + sl.n[2], tot = e2 + sl.n[3];
+                    const uint32_t cur_l = __hip_atomic_load(&sl.cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long avail = __ballot(cur_l < tot);
+                    if (!avail) { exhausted = true; break; }
+                    const uint32_t rot = cur_shard & 63u;
+                    const unsigned long long rmask = rot ? ((avail >> rot) | (avail << (64u - rot))) : avail;
+                    cur_shard = ((uint32_t)(__ffsll((long long)rmask) - 1) + rot) & 63u;
+                    sh_e0 = __shfl(e0, (int)cur_shard, 64); sh_e1 = __shfl(e1, (int)cur_shard, 64);
+                    sh_e2 = __shfl(e2, (int)cur_shard, 64); sh_total = __shfl(tot, (int)cur_shard, 64);
+                    have_shard = true;
+                }
+                if (chunk_pos < chunk_end) {
+                    // the next (up to) kRing2 rays of the chunk, set up by as many lanes at once
+                    const uint32_t n = min(kRing2, chunk_end - chunk_pos);
+                    bool ok = false;
+                    float4 R0 = float4{0, 0, 0, 0}, R1 = R0, R2 = R0, R3 = R0;
+                    uint2 RL = uint2{kNoHit, kNoHit};
+                    if (lane < n) {
+                        const uint32_t idx = chunk_pos + lane;
+                        const size_t region = (size_t)cur_shard * P.list_cap;
+                        const bool sh = idx >= sh_e1;
+                        const size_t g = idx < sh_e0 ? region + idx : idx < sh_e1 ? cls_stride + region + (idx - sh_e0)
+                                       : idx < sh_e2 ? 2u * cls_stride + region + (idx - sh_e1) : 3u * cls_stride + region + (idx - sh_e2);
+                        const float4 ro = ldnt(&recA[g]), rd = ldnt(&recB[g]);
+                        uint4 rc = uint4{0, 0, 0, 0};
+                        if (sh) rc = ldnt(&recC[g]);
+                        uint32_t r_slot;
+                        float r_tmax;
+                        ok = true;
+                        if (sh) {
+                            r_slot = rc.x & kWfListSlot; r_tmax = rd.w;   // (the mark on rc.x is tail mode's business)
+                            RL = uint2{rc.y, rc.z};                      // the light's primitive index and slot
+                        } else {
+                            r_slot = f_bits(rd.w) & kWfListSlot; r_tmax = CRT_INFINITY;
+                            if (f_bits(rd.w) & kWfListAlsoExt) ok = false;   // non-finite ray, already resolved by k_wf_shade
+                            else if (nprim == 0u) { g_hit[r_slot] = float2{r_tmax, bits_f(kNoHit)}; ok = false; }
+                        }
+                        const float tiny = 1.0e-20f;
+                        f3 i3;
+                        i3.x = 1.0f / (abs_(rd.x) > tiny ? rd.x : __builtin_copysignf(tiny, rd.x));
+                        i3.y = 1.0f / (abs_(rd.y) > tiny ? rd.y : __builtin_copysignf(tiny, rd.y));
+                        i3.z = 1.0f / (abs_(rd.z) > tiny ? rd.z : __builtin_copysignf(tiny, rd.z));
+                        // plane = qbase + q*qscale  =>  t = q*(qscale*id) + (qbase*id - o*id): one fma per plane
+                        const f3 oi = f3{fma_(qbase.x, i3.x, -(ro.x * i3.x)), fma_(qbase.y, i3.y, -(ro.y * i3.y)), fma_(qbase.z, i3.z, -(ro.z * i3.z))};
+                        R0 = ro;
+                        R1 = float4{rd.x, rd.y, rd.z, bits_f(r_slot | (sh ? 0x80000000u : 0u))};
+                        // (the sign of the raw reciprocal picks the near planes: kept in the w of R3, the scaled one may be +-0)
+                        R2 = float4{qscale.x * i3.x, qscale.y * i3.y, qscale.z * i3.z, r_tmax};
+                        R3 = float4{oi.x, oi.y, oi.z, bits_f((i3.x < 0.0f ? 1u : 0u) | (i3.y < 0.0f ? 2u : 0u) | (i3.z < 0.0f ? 4u : 0u))};
+                    }
+                    const unsigned long long mk = __ballot(ok);
+                    if (ok) {
+                        const uint32_t e = mbcnt64(mk);
+                        ring[0][e] = R0; ring[1][e] = R1; ring[2][e] = R2; ring[3][e] = R3; ring_l[e] = RL;
+                    }
+                    ring_head = 0; ring_n = (uint32_t)__popcll(mk);
+                    chunk_pos += n;
+                    if (COUNT) { d_refill++; d_refill_lanes += ring_n; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (ring_n > 0u) {
+                const uint32_t give = min((uint32_t)nidle, ring_n);
+                const uint32_t my = mbcnt64(idle);
+                if (!active && my < give) {
+                    const uint32_t e = ring_head + my;                   // (the ring is refilled from 0, only when empty: no wrap)
+                    const float4 R0 = ring[0][e], R1 = ring[1][e], R2 = ring[2][e], R3 = ring[3][e];
+                    const uint2 RL = ring_l[e];
+                    o = xyz(R0); excl = f_bits(R0.w);
+                    d = xyz(R1); slot = f_bits(R1.w) & kWfListSlot; shadow = (f_bits(R1.w) >> 31) != 0u;
+                    id = xyz(R2); t_max = R2.w;
+                    oid = xyz(R3);
+                    const uint32_t sg = f_bits(R3.w);
+                    gx = (sg & 1u) != 0u; gy = (sg & 2u) != 0u; gz = (sg & 4u) != 0u;
+                    b_index = RL.x; b_slot = RL.y; b_slot_in = b_slot;
+                    cell[lane] = hit_key(t_max, b_index); cslot[lane] = b_slot;
+                    node = root; sp = 0; pend = 0;
+                    active = true;
+                }
+                ring_head += give; ring_n -= give;
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted && ring_n == 0u) break;
+            continue;
+        }
+
+#pragma unroll 1
+        for (int pass = 0; pass < 64; pass++) {
+            // A lane that reaches a leaf puts it aside (one per lane) and goes on with the next node of its stack: the
+            // closest hit does not depend on the order, only t_max shrinks a little later.
+            if (active && node < 0 && pend == 0 && sp > 0) {
+                pend = node;
+                sp--; node = stack_pop2(stk, ovf, ovl, sp);
+            }
+            const bool inner = active && node >= 0 && node != kNoNode;
+            const bool leaf = active && (node < 0 || pend != 0);
+            // (an active lane is on an inner node, or holds a leaf, or both: nb - ni lanes cannot take an inner-node step)
+            const int ni = __popcll(__ballot(inner)), nl = __popcll(__ballot(leaf)), nb = __popcll(__ballot(active));
+            if (nb == 0) break;
+            if (pass > 0 && 64 - nb >= CRT_WF_PICK_AT && (ring_n > 0u || !exhausted)) break;   // enough idle lanes: pick up first
+            if (nl >= CRT_WF_LEAF2_AT || ni == 0 || nb - ni >= CRT_WF_STALL_AT) {
+                // ---- leaf pass: the waiting leaves' primitives as one compacted round of tasks
+                const int lf = pend != 0 ? pend : node;                  // the leaf this lane offers (the postponed one first)
+                const uint32_t cnt = leaf ? ((~(uint32_t)lf) & 7u) + 1u : 0u;
+                const unsigned long long c0 = __ballot((cnt & 1u) != 0u), c1 = __ballot((cnt & 2u) != 0u), c2 = __ballot((cnt & 4u) != 0u), c3 = __ballot((cnt & 8u) != 0u);
+                const uint32_t pre = mbcnt64(c0) + 2u * mbcnt64(c1) + 4u * mbcnt64(c2) + 8u * mbcnt64(c3);
+                const bool incl = leaf && pre + cnt <= 64u;              // (whole leaves only; the included lanes are a prefix of the leaf lanes)
+                const unsigned long long mi = __ballot(incl);
+                const uint32_t T = (uint32_t)(__popcll(c0 & mi) + 2 * __popcll(c1 & mi) + 4 * __popcll(c2 & mi) + 8 * __popcll(c3 & mi));
+                const uint32_t first = (~(uint32_t)lf) >> 3;
+                if (incl) {                                              // (the builders' leaves hold one to four primitives as a rule)
+                    tasks[pre] = lane;
+                    if (cnt > 1u) tasks[pre + 1u] = lane | (1u << 6);
+                    if (cnt > 2u) tasks[pre + 2u] = lane | (2u << 6);
+                    if (cnt > 3u) tasks[pre + 3u] = lane | (3u << 6);
+                    for (uint32_t i = 4; i < cnt; i++) tasks[pre + i] = lane | (i << 6);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (COUNT) { d_leaf_it++; d_leaf_act += T; d_prim_it += 1u; }
+                // every lane shuffles (a bpermute reads active lanes only); lanes beyond T run on their own ray and do nothing
+                const uint32_t tk = lane < T ? tasks[lane] : lane;
+                const int owner = (int)(tk & 63u);
+                const uint32_t ps = (uint32_t)__shfl((int)first, owner, 64) + (tk >> 6);
+                const f3 to = f3{__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64)};
+                const f3 td = f3{__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64)};
+                const uint32_t t_excl = (uint32_t)__shfl((int)excl, owner, 64);
+                bool acc = false;
+                unsigned long long key = 0;
+                if (lane < T) {
+                    const unsigned long long cur = cell[owner];
+                    float tm = bits_f((uint32_t)(cur >> 32));
+                    const uint32_t low = (uint32_t)cur;
+                    uint32_t bi = low == 0xFFFFFFFFu ? kNoHit : 0xFFFFFFFEu - low;
+                    const uint32_t bs0 = low == 0xFFFFFFFFu ? kNoHit : 0xFFFFFFFEu;     // "some hit" (no primitive has that slot)
+                    uint32_t bs = bs0;
+                    const float4 A = prim[3 * (size_t)ps + 0], B = prim[3 * (size_t)ps + 1], C = prim[3 * (size_t)ps + 2];
+                    if ((f_bits(A.w) & 3u) == 2u) tri_test(A, B, C, ps, to, td, t_excl, t_min, hit_pad, tm, bi, bs);
+                    else hit_test<false>(S, ps, to, td, t_excl, t_min, tm, bi, bs);
+                    acc = bs != bs0;
+                    if (acc) {
+                        key = hit_key(tm, bi);
+                        atomicMin(&cell[owner], key);
+                    }
+                    if (COUNT) c_prims++;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (acc && cell[owner] == key) cslot[owner] = ps;        // the round's winner for that ray names its slot
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (incl) {
+                    const unsigned long long v = cell[lane];
+                    const uint32_t low = (uint32_t)v;
+                    t_max = bits_f((uint32_t)(v >> 32));
+                    b_index = low == 0xFFFFFFFFu ? kNoHit : 0xFFFFFFFEu - low;
+                    b_slot = cslot[lane];
+                    if (pend != 0) pend = 0;                             // the postponed leaf went first
+                    else if (sp > 0) { sp--; node = stack_pop2(stk, ovf, ovl, sp); }
+                    else node = kNoNode;
+                    bool done = false;
+                    if (shadow && b_slot != b_slot_in) done = true;      // any-hit: something beats the light
+                    else if (node == kNoNode && pend == 0) done = true;
+                    if (done) {
+                        if (shadow) stnt(&g_vis[slot], (b_slot == b_slot_in) ? 1u : 0u);
+                        else stnt(&g_hit[slot], float2{t_max, bits_f(b_slot)});
+                        active = false;
+                    }
+                }
+            } else {
+                if (COUNT) { d_inner_it++; d_inner_act += (uint32_t)ni; }
+                if (inner) {
+                    float k0, k1, k2, k3;
+                    int r0, r1, r2, r3;
+                    // one 64-byte node: 16-bit plane coordinates, near / far plane picked by the ray's signs
+                    const uint4 *nq = (const uint4 *)((const char *)nodesq + ((uint32_t)node << 6));   // (32-bit offset: the tree is below 4 GB)
+                    const uint4 Q0 = nq[0], Q1 = nq[1], Q2 = nq[2], Q3 = nq[3];
+                    const uint32_t nxa = gx ? Q1.z : Q0.x, nxb = gx ? Q1.w : Q0.y, fxa = gx ? Q0.x : Q1.z, fxb = gx ? Q0.y : Q1.w;
+                    const uint32_t nya = gy ? Q2.x : Q0.z, nyb = gy ? Q2.y : Q0.w, fya = gy ? Q0.z : Q2.x, fyb = gy ? Q0.w : Q2.y;
+                    const uint32_t nza = gz ? Q2.z : Q1.x, nzb = gz ? Q2.w : Q1.y, fza = gz ? Q1.x : Q2.z, fzb = gz ? Q1.y : Q2.w;
+#define CRT_QBOX(K, NXQ, NYQ, NZQ, FXQ, FYQ, FZQ) { \
+                        const float tn_ = __builtin_fmaxf(__builtin_fmaxf(fma_((float)(NXQ), id.x, oid.x), fma_((float)(NYQ), id.y, oid.y)), \
+                                                          __builtin_fmaxf(fma_((float)(NZQ), id.z, oid.z), t_min)); \
+                        const float tf_ = __builtin_fminf(__builtin_fminf(fma_((float)(FXQ), id.x, oid.x), fma_((float)(FYQ), id.y, oid.y)), \
+                                                          __builtin_fminf(fma_((float)(FZQ), id.z, oid.z), t_max)); \
+                        K = (tn_ <= tf_ * 1.0000005f) ? tn_ : 3.0e38f; }
+                    CRT_QBOX(k0, nxa & 0xFFFFu, nya & 0xFFFFu, nza & 0xFFFFu, fxa & 0xFFFFu, fya & 0xFFFFu, fza & 0xFFFFu)
+                    CRT_QBOX(k1, nxa >> 16, nya >> 16, nza >> 16, fxa >> 16, fya >> 16, fza >> 16)
+                    CRT_QBOX(k2, nxb & 0xFFFFu, nyb & 0xFFFFu, nzb & 0xFFFFu, fxb & 0xFFFFu, fyb & 0xFFFFu, fzb & 0xFFFFu)
+                    CRT_QBOX(k3, nxb >> 16, nyb >> 16, nzb >> 16, fxb >> 16, fyb >> 16, fzb >> 16)
+#undef CRT_QBOX
+                    r0 = (int)Q3.x; r1 = (int)Q3.y; r2 = (int)Q3.z; r3 = (int)Q3.w;
+                    if (COUNT) c_nodes += 4;
+                    // sort the four (key, ref) pairs by entry distance: 5 compare-exchanges
+#define CRT_CAS(ka, ra, kb, rb) { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; kb = sw_ ? ka : kb; ka = tk_; \
+                                  const int tr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = tr_; }
+                    CRT_CAS(k0, r0, k1, r1) CRT_CAS(k2, r2, k3, r3) CRT_CAS(k0, r0, k2, r2) CRT_CAS(k1, r1, k3, r3) CRT_CAS(k1, r1, k2, r2)
+#undef CRT_CAS
+                    if (k0 < 3.0e38f) {
+                        // descend into the nearest; the others wait on the stack, farthest pushed first
+                        if (k3 < 3.0e38f) { if (sp < kStk2) stk[sp * 64] = r3; else ovf[(size_t)(sp - kStk2) * ovl] = r3; sp++; }
+                        if (k2 < 3.0e38f) { if (sp < kStk2) stk[sp * 64] = r2; else ovf[(size_t)(sp - kStk2) * ovl] = r2; sp++; }
+                        if (k1 < 3.0e38f) { if (sp < kStk2) stk[sp * 64] = r1; else ovf[(size_t)(sp - kStk2) * ovl] = r1; sp++; }
+                        node = r0;
+                    } else if (sp > 0) {
+                        sp--; node = stack_pop2(stk, ovf, ovl, sp);
+                    } else {
+                        node = kNoNode;                                  // nothing left to walk ...
+                        if (pend == 0) {                                 // ... and no postponed leaf either: the ray is through
+                            if (shadow) stnt(&g_vis[slot], (b_slot == b_slot_in) ? 1u : 0u);
+                            else stnt(&g_hit[slot], float2{t_max, bits_f(b_slot)});
+                            active = false;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_NODES, c_nodes);
+        wave_add(ctl->counters[blockIdx.x % kWfShards] + CRT_CNT_PRIMS, c_prims);
+        if (lane == 0) {
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 8, (unsigned long long)d_inner_it); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 9, (unsigned long long)d_inner_act);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 10, (unsigned long long)d_leaf_it); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 11, (unsigned long long)d_leaf_act);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 12, (unsigned long long)d_prim_it); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 13, (unsigned long long)d_scans); atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 14, (unsigned long long)d_refill);
+            atomicAdd(ctl->counters[blockIdx.x % kWfShards] + 15, (unsigned long long)d_refill_lanes);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ finish
 // The last few paths of a batch (no work left, a few thousand slots alive at most): one lane
 // per remaining slot runs its path to the end -- trace the pending rays itself (plain BVH2 walk,
@@ -1325,6 +1690,12 @@ __global__ __launch_bounds__(64) void k_wf_resolve(const WfParams P, uint32_t la
     for (uint32_t s = 0; s < P.n_samples; s++) {
         const float4 v = ldnt(&staging[(size_t)s * npix + pix]);
         acc = acc + f3{v.x, v.y, v.z};                           // :108, in sample order
+        if (P.frames) {
+            // every sample's frame, as the reference shows it (one dispatch + blit per sample, src/main.js:597-620): kept
+            // in a ring so that a display loop can show each frame index once while the batches run ahead of it
+            const uint32_t smp = last_sample - P.n_samples + 1u + s;
+            P.frames[(size_t)((smp - 1u) % P.frame_ring) * npix + pix] = tonemap_rgba8(acc, (float)smp);
+        }
     }
     P.accum[pix] = float4{acc.x, acc.y, acc.z, a4.w};
     if (P.n_samples > 0) P.rgba[pix] = tonemap_rgba8(acc, (float)last_sample);
@@ -1403,6 +1774,11 @@ hipError_t wf_launch_trace(const WfParams &P, uint32_t it, uint32_t trace_blocks
 {
     const dim3 g(trace_blocks), b(64);
     const int q = !CRT_WF_BVH4 ? 0 : P.sc.nodes8q != nullptr ? 2 : P.sc.nodes4q != nullptr ? 1 : 0;
+    if (q == 1 && P.trace_form == 2u) {                          // the regrouped form (quantised 4-wide tree only)
+        if (P.count) hipLaunchKernelGGL((k_wf_trace2<true>), g, b, 0, s, P, it);
+        else hipLaunchKernelGGL((k_wf_trace2<false>), g, b, 0, s, P, it);
+        return hipGetLastError();
+    }
     if (P.count) {
         if (q == 2) hipLaunchKernelGGL((k_wf_trace<true, 2>), g, b, 0, s, P, it);
         else if (q == 1) hipLaunchKernelGGL((k_wf_trace<true, 1>), g, b, 0, s, P, it);

@@ -127,6 +127,27 @@ class Renderer:
         self._chk(self._lib.crt_read_rgba8(self._h, out.ctypes.data))
         return out
 
+    def read_latest_rgba8(self):
+        """(frame, sample index): the newest complete frame in stream order, without finishing what is in flight."""
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.uint8)
+        s = C.c_uint32()
+        self._chk(self._lib.crt_read_latest_rgba8(self._h, out.ctypes.data, C.byref(s)))
+        return out, s.value
+
+    @property
+    def latest_sample(self) -> int:
+        v = C.c_uint32()
+        self._chk(self._lib.crt_latest_sample(self._h, C.byref(v)))
+        return v.value
+
+    def read_sample_rgba8(self, sample: int) -> np.ndarray:
+        """The frame after exactly `sample` samples (option frame_ring = F keeps the last F)."""
+        _, _, tw, th = self.tile
+        out = np.empty((th, tw, 4), np.uint8)
+        self._chk(self._lib.crt_read_sample_rgba8(self._h, int(sample), out.ctypes.data))
+        return out
+
     def write_accum(self, accum: np.ndarray, sample: int):
         a = np.ascontiguousarray(accum, np.float32)
         _, _, tw, th = self.tile
@@ -146,6 +167,63 @@ class Renderer:
 
     def set_stream(self, hip_stream: int | None):
         self._chk(self._lib.crt_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        return self
+
+    # -- multi-GPU: the frame across the ranks of a communicator (include/crt.h, "Multi-GPU")
+    @staticmethod
+    def comm_unique_id(local: bool = False) -> bytes:
+        """128-byte communicator id: RCCL (one rank makes it, every rank gets it) or, local=True, the in-process transport."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.crt_comm_unique_id(buf, 1 if local else 0)
+        if rc != 0:
+            raise CrtError(rc, (lib.crt_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        if len(comm_id) != 128:
+            raise ValueError("communicator id must be 128 bytes")
+        self._chk(self._lib.crt_comm_init(self._h, C.create_string_buffer(comm_id, 128), int(rank), int(world)))
+        return self
+
+    def comm_partition(self, band_rows: int = 8):
+        self._chk(self._lib.crt_comm_partition(self._h, int(band_rows)))
+        return self
+
+    def gather(self, rgba8: bool = True, accum: bool = False):
+        self._chk(self._lib.crt_gather(self._h, (1 if rgba8 else 0) | (2 if accum else 0)))
+        return self
+
+    @property
+    def image_size(self):
+        out = (C.c_uint32 * 2)()
+        self._chk(self._lib.crt_image_size(self._h, out))
+        return int(out[0]), int(out[1])
+
+    def read_frame_rgba8(self) -> np.ndarray:
+        W, H = self.image_size
+        out = np.empty((H, W, 4), np.uint8)
+        self._chk(self._lib.crt_read_frame_rgba8(self._h, out.ctypes.data))
+        return out
+
+    def read_frame_accum(self) -> np.ndarray:
+        W, H = self.image_size
+        out = np.empty((H, W, 4), np.float32)
+        self._chk(self._lib.crt_read_frame_accum(self._h, out.ctypes.data))
+        return out
+
+    def frame_device_buffers(self):
+        a, r = C.c_void_p(), C.c_void_p()
+        self._chk(self._lib.crt_frame_device_buffers(self._h, C.byref(a), C.byref(r)))
+        return a.value, r.value
+
+    def comm_info(self) -> dict:
+        out = (C.c_int * 4)()
+        self._chk(self._lib.crt_comm_info(self._h, out))
+        return dict(rank=out[0], world=out[1], transport={0: "rccl", 1: "local"}.get(out[2]), rows=out[3])
+
+    def comm_destroy(self):
+        self._chk(self._lib.crt_comm_destroy(self._h))
         return self
 
     # -- measurement

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 1
+#define CRT_ABI_VERSION 2
 
 enum {
     CRT_OK = 0,
@@ -141,6 +141,19 @@ int crt_tile(crt_ctx *ctx, uint32_t out[4]);
  * pad -- the 16-byte stride of array<vec3<f32>>); rgba8: tw*th*4 bytes. */
 int crt_read_accum(crt_ctx *ctx, float *out);
 int crt_read_rgba8(crt_ctx *ctx, uint8_t *out);
+/* The display step of the reference's frame loop (src/main.js:597-620 shows EVERY sample's frame: compute pass, blit,
+ * requestAnimationFrame) without stopping the pipeline:
+ *   crt_read_latest_rgba8   the newest COMPLETE frame in stream order and its sample index -- no flush: batches in
+ *                           flight stay in flight (crt_read_rgba8 finishes everything first);
+ *   crt_latest_sample       that index alone (non-blocking; retires what has finished meanwhile);
+ *   crt_read_sample_rgba8   the frame as it was after exactly `sample` samples, from a ring of the last F frames (option
+ *                           "frame_ring" = F, set before tracing; k_wf_resolve then stores every sample's frame, bit-identical
+ *                           to a synced crt_trace(1) loop).  Waits only for the batch that holds the sample; a display loop
+ *                           that requests frames a cohort ahead of the one it shows (host/display_loop.js) sees every frame
+ *                           index exactly once while small calls are still merged into cohorts. */
+int crt_read_latest_rgba8(crt_ctx *ctx, uint8_t *out, uint32_t *sample);
+int crt_latest_sample(crt_ctx *ctx, uint32_t *out);
+int crt_read_sample_rgba8(crt_ctx *ctx, uint32_t sample, uint8_t *out);
 /* Restore an accumulator + sample count (checkpoint/resume). */
 int crt_write_accum(crt_ctx *ctx, const float *in, uint32_t sample);
 
@@ -152,6 +165,51 @@ int crt_device_buffers(crt_ctx *ctx, void **accum_dev, void **rgba8_dev);
 int crt_bind_output(crt_ctx *ctx, void *accum_dev, void *rgba8_dev);
 /* Enqueue on the caller's hipStream_t instead of the context's own. */
 int crt_set_stream(crt_ctx *ctx, void *hip_stream);
+
+/* The context's device ordinal and the HIP stream it enqueues on (hipStream_t as void*), the full image's size
+ * (out[2] = W, H): for code that composes with the context from outside, like the gather below. */
+int crt_get_device(crt_ctx *ctx, int *out);
+int crt_get_stream(crt_ctx *ctx, void **out);
+int crt_image_size(crt_ctx *ctx, uint32_t out[2]);
+
+/* ------------------------------------------------------------------ Multi-GPU: the frame across the ranks of a communicator
+ * The reference drives ONE GPUDevice (src/main.js:8-9) and has no exchange step.  Here the frame is partitioned by rows
+ * across `world` contexts -- one per GPU, as a rule one process per GPU -- the scene replicated, and the path's only
+ * exchange is the gather of the finished strips: an RCCL all-gather over xGMI issued from libcrt on the context's stream
+ * (SURVEY 8e).  Pixels depend on their global coordinates only (ComputeShader.wgsl:85-86,98), so the assembled frame is
+ * bit-identical for every world size.
+ *
+ *   crt_comm_unique_id(id, CRT_COMM_RCCL)      on one rank; hand the 128 bytes to the others (IPC, a file, a socket)
+ *   crt_comm_init(ctx, id, rank, world)        every rank, after crt_create (collective for RCCL)
+ *   crt_upload_scene(ctx, ...)                 the same scene on every rank
+ *   crt_comm_partition(ctx, band_rows)         this rank's rows: bands of band_rows rows dealt round-robin (8 balances
+ *                                              regions of different path length), 0 = contiguous strips; the context then
+ *                                              renders into strip buffers owned by the communicator (resets the accumulator)
+ *   crt_build_accel; loop { crt_trace(ctx, n); crt_gather(ctx, CRT_GATHER_RGBA8); }     every rank
+ *   crt_sync(ctx); crt_gather(ctx, CRT_GATHER_RGBA8 | CRT_GATHER_ACCUM);
+ *   crt_read_frame_rgba8 / crt_read_frame_accum(ctx, out)       any rank: the whole W x H frame
+ *
+ * crt_gather is asynchronous and stream-ordered like crt_trace: it ships what the strip holds THEN -- after crt_sync
+ * every sample requested so far, in a pipelined loop the latest complete frame (crt_trace's contract for bound outputs).
+ * CRT_COMM_LOCAL is the same interface for contexts of ONE process (any devices): strips are exchanged with
+ * device-to-device copies, no RCCL; every rank posts its crt_gather before any rank reads the frame. */
+#define CRT_COMM_ID_BYTES 128
+enum { CRT_COMM_RCCL = 0, CRT_COMM_LOCAL = 1 };
+enum { CRT_GATHER_RGBA8 = 1, CRT_GATHER_ACCUM = 2 };
+int crt_comm_unique_id(void *out_id /* CRT_COMM_ID_BYTES */, int transport);
+int crt_comm_init(crt_ctx *ctx, const void *id, int rank, int world);
+int crt_comm_partition(crt_ctx *ctx, uint32_t band_rows);
+int crt_gather(crt_ctx *ctx, int what);
+int crt_read_frame_rgba8(crt_ctx *ctx, uint8_t *out /* W*H*4, row 0 = top */);
+int crt_read_frame_accum(crt_ctx *ctx, float *out /* W*H*4 floats */);
+/* Device pointers of the assembled frame of the latest gather (valid until the next crt_comm_partition). */
+int crt_frame_device_buffers(crt_ctx *ctx, void **accum_dev, void **rgba8_dev);
+/* out[4] = rank, world, transport (-1: no communicator), rows of this rank. */
+int crt_comm_info(crt_ctx *ctx, int out[4]);
+int crt_comm_destroy(crt_ctx *ctx);          /* also done by crt_destroy */
+/* The row layout itself (no GPU involved): the rows of the H-row frame that belong to `part` of `parts`, in local order;
+ * n_rows receives their number, global_rows (may be NULL) their indices.  band_rows = 0: contiguous strips. */
+int crt_layout_rows(uint32_t H, uint32_t band_rows, uint32_t parts, uint32_t part, uint32_t *n_rows, uint32_t *global_rows);
 
 /* Counters accumulate over crt_trace calls while enabled (off by default: the
  * counting kernel variant is slower). */
@@ -179,6 +237,8 @@ int crt_last_kernel_ms(crt_ctx *ctx, float *ms, uint32_t *launches);
  * a time), "wf_ahead" (iterations in flight per pipe before the call waits), "wf_feed_pct", "wf_finish_at",
  * "wf_flush_at", "wf_side_ppw", "wf_flush_ppw", "wf_tail_walk": pipeline tuning;
  * "quantize", "wf_width" (4 | 8: node width of the wavefront traversal; at crt_build_accel);
+ * "wf_trace_form" (2: ray ring + primitive tasks, default; 1: the first traversal kernel); "frame_ring" = F (keep the
+ * rgba8 frame of each of the last F samples for crt_read_sample_rgba8; 0 = off);
  * "time_kernels"; "debug_fail_alloc" = k (test hook: the k-th device allocation from now on reports
  * out of memory).  Setting an option first finishes what is in flight. */
 int crt_set_option(crt_ctx *ctx, const char *name, int64_t value);

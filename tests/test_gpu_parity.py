@@ -309,20 +309,21 @@ def test_checkpoint_resume(renderer):
 
 
 def test_every_pipeline_form_gives_the_same_image(renderer, orc):
-    """Wavefront pipeline with quantised 4-wide nodes (default), with quantised 8-wide nodes, with plain
+    """Wavefront pipeline with quantised 4-wide nodes (default: the regrouped traversal kernel, ray ring + primitive
+    tasks), the same with the first form of the traversal kernel, with quantised 8-wide nodes, with plain
     4-wide nodes, and the single-kernel form on the BVH2: one image, bit for bit (and equal to the oracle
     on a crop)."""
     ps = _mixed_scene(640, 360)
     imgs = []
     try:
-        for pipeline, quant, width in [(1, 1, 4), (1, 1, 8), (1, 0, 4), (0, 1, 4)]:
-            renderer.set_option("pipeline", pipeline).set_option("quantize", quant).set_option("wf_width", width)
+        for pipeline, quant, width, form in [(1, 1, 4, 2), (1, 1, 4, 1), (1, 1, 8, 2), (1, 0, 4, 2), (0, 1, 4, 2)]:
+            renderer.set_option("pipeline", pipeline).set_option("quantize", quant).set_option("wf_width", width).set_option("wf_trace_form", form)
             acc, rgba = render(renderer, ps, 5)
             imgs.append((acc, rgba))
             st = renderer.accel_stats()
             assert st["width"] == (width if pipeline else 2) and st["bytes_per_box"] == (16 if (pipeline and quant) else 32)
     finally:
-        renderer.set_option("pipeline", 1).set_option("quantize", 1).set_option("wf_width", 4)
+        renderer.set_option("pipeline", 1).set_option("quantize", 1).set_option("wf_width", 4).set_option("wf_trace_form", 2)
     for acc, rgba in imgs[1:]:
         assert np.array_equal(bits(acc), bits(imgs[0][0])) and np.array_equal(rgba, imgs[0][1])
     rect = (300, 170, 340, 200)
@@ -798,6 +799,91 @@ def test_out_of_memory_is_reported_and_the_context_recovers(orc):
             finally:
                 r.set_option("debug_fail_alloc", 0)
                 r.close()
+
+
+def test_every_frame_of_a_pipelined_run_can_be_shown_once(renderer, orc):
+    """The display step of the reference's loop (src/main.js:597-620 shows every sample's frame) without stopping the
+    pipeline: with option frame_ring the resolve pass keeps the rgba8 frame of every sample; crt_read_sample_rgba8(k)
+    returns frame k -- bit-identical to the oracle's frame after k samples -- while calls run ahead of the reads and are
+    merged into cohorts; crt_read_latest_rgba8 returns a complete frame and its index without flushing."""
+    from computeraytracer_amd import cornell
+    from computeraytracer_amd._lib import CrtError
+    W = H = 200
+    ps = cornell(W, H)
+    sc = orc.Scene.from_packed(ps)
+    want = {}
+    try:
+        renderer.upload(ps).build_accel("bvh2").set_option("frame_ring", 24).set_option("wf_cohort", 8)
+        lag, frames, shown = 10, 40, []
+        for k in range(1, frames + 1):
+            renderer.frame(1)
+            if k > lag:
+                shown.append((k - lag, renderer.read_sample_rgba8(k - lag)))
+            if k == 25:
+                img, s = renderer.read_latest_rgba8()                 # no flush: some complete frame at most 25 samples old
+                assert 0 < s <= 25 and renderer.sample == 25
+                want[s] = want.get(s) or sc.render(s)[1]
+                assert np.array_equal(img, want[s])
+        for k in range(frames - lag + 1, frames + 1):
+            shown.append((k, renderer.read_sample_rgba8(k)))
+        assert [k for k, _ in shown] == list(range(1, frames + 1))
+        for k, img in shown:
+            if k in (1, 2, 7, 8, 9, 16, 17, 31, 39, 40):             # (the oracle renders k samples from scratch each time)
+                assert np.array_equal(img, sc.render(k)[1]), k
+        with pytest.raises(CrtError, match="left the ring"):
+            renderer.read_sample_rgba8(5)
+        renderer.sync()
+        assert renderer.latest_sample == frames
+        assert_same_image(renderer.read_accum(), renderer.read_rgba8(), *sc.render(frames)[:2])
+    finally:
+        renderer.set_option("frame_ring", 0).set_option("wf_cohort", 16)
+
+
+# ------------------------------------------------------------------ multi-GPU through the C ABI
+@pytest.mark.parametrize("world,band", [(2, 8), (3, 0), (4, 5)])
+def test_native_gather_assembles_the_single_gpu_frame(orc, world, band):
+    """The multi-GPU path of the C ABI (crt_comm_*, crt_gather, crt_read_frame_*) on ONE GPU: `world` contexts on device 0
+    joined by the in-process transport (device-to-device copies stand where RCCL's all-gather does; partition, strip
+    buffers, stream ordering and assembly are the same code).  Each rank renders its rows; the assembled frame equals
+    the oracle's, bit for bit, on every rank -- mid-run gathers of a pipelined loop included."""
+    from computeraytracer_amd import Renderer, cornell
+    W, H, spp = 136, 93, 3                           # (H not a multiple of the band, nor of the world size)
+    ps = cornell(W, H)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(2 * spp)
+    cid = Renderer.comm_unique_id(local=True)
+    rs = [Renderer(0) for _ in range(world)]
+    try:
+        for k, r in enumerate(rs):
+            r.comm_init(cid, k, world).upload(ps).comm_partition(band).build_accel("bvh2")
+            assert r.comm_info() == dict(rank=k, world=world, transport="local", rows=r.tile[3])
+        assert sum(r.tile[3] for r in rs) == H
+        for r in rs:
+            r.frame(spp).gather(rgba8=True)                          # a gather in the middle of the run (no sync)
+        for r in rs:
+            r.frame(spp).sync().gather(rgba8=True, accum=True)
+        for r in rs:                                                 # all_gather: every rank holds the frame
+            assert_same_image(r.read_frame_accum(), r.read_frame_rgba8(), acc_o, rgba_o)
+        with pytest.raises(Exception, match="has not posted"):
+            rs[0].gather(rgba8=True).read_frame_rgba8()              # a rank alone cannot read a frame the others did not post
+    finally:
+        for r in rs:
+            r.close()
+
+
+def test_native_gather_over_rccl_single_rank():
+    """The RCCL transport itself on the one GPU the test box has: librccl is loaded on demand, ncclCommInitRank and
+    ncclAllGather run with world = 1, and the frame read through the communicator equals the context's own."""
+    from computeraytracer_amd import Renderer, cornell
+    ps = cornell(64, 48)
+    r = Renderer(0)
+    try:
+        r.comm_init(Renderer.comm_unique_id(local=False), 0, 1).upload(ps).comm_partition(8).build_accel("bvh2")
+        assert r.comm_info()["transport"] == "rccl"
+        r.frame(2).sync().gather(rgba8=True, accum=True)
+        a, g = r.read_frame_accum(), r.read_frame_rgba8()
+        assert np.array_equal(bits(a), bits(r.read_accum())) and np.array_equal(g, r.read_rgba8())
+    finally:
+        r.close()
 
 
 # ------------------------------------------------------------------ error behaviour

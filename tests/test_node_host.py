@@ -57,3 +57,41 @@ def test_async_napi_keeps_the_event_loop_free(tmp_path):
     info = json.loads(out.stdout.strip().splitlines()[-1])
     assert info["equal"] and info["busy"] and info["rejected"] and info["sample"] == 64
     assert info["ticks"] > 10, info
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_display_loop_shows_every_frame_once(tmp_path):
+    """host/display_loop.js: trace(1) per frame, the display lagging by a cohort and a half; every frame index shown once,
+    in order, each equal to the frame a synchronous trace(1); sync(); readRgba8() loop shows."""
+    out = subprocess.run([NODE, os.path.join(ROOT, "host", "display_loop.js"), "--width", "160", "--height", "120", "--frames", "70",
+                          "--lag", "24", "--ring", "48", "--check", "1"], capture_output=True, text=True, check=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["shown"] == 70 and info["every_index_once_in_order"] and info["equal_to_synced_loop"] and info["latest"] == 70, info
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+@pytest.mark.parametrize("world,band", [(2, 8), (3, 0)])
+def test_node_multi_gpu_host_local_transport(tmp_path, orc, world, band):
+    """host/multi.js --local: `world` ranks in one Node process on device 0 through the addon's multi-GPU calls
+    (commInit / commPartition / gather / readFrameRgba8); the assembled frame is the oracle's."""
+    from computeraytracer_amd import cornell
+    cmd = [NODE, os.path.join(ROOT, "host", "multi.js"), "--gpus", str(world), "--local", "--width", "120", "--height", "77",
+           "--spp", "2", "--frames", "2", "--band", str(band), "--dump", str(tmp_path / "frame.bin")]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["gpus"] == world and sum(info["rows"]) == 77 and info["samples"] == 4
+    rgba = np.frombuffer((tmp_path / "frame.bin").read_bytes(), np.uint8).reshape(77, 120, 4)
+    _, rgba_o, _ = orc.Scene.from_packed(cornell(120, 77)).render(4)
+    assert np.array_equal(rgba, rgba_o)
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_multi_gpu_host_forked_worker_over_rccl(tmp_path):
+    """host/multi.js with one forked worker per GPU (here: the box's one GPU, world = 1): the parent never touches the
+    GPU, rank 0 makes the RCCL id, the worker renders, gathers through RCCL and reports."""
+    cmd = [NODE, os.path.join(ROOT, "host", "multi.js"), "--gpus", "1", "--width", "96", "--height", "64", "--spp", "2", "--frames", "2",
+           "--out", str(tmp_path / "f.ppm")]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True, timeout=120)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["transport"] == "rccl" and info["rows"] == [64] and info["every_rank_holds_the_same_frame"]
+    assert (tmp_path / "f.ppm").read_bytes().startswith(b"P6\n96 64\n255\n")
