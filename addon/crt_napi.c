@@ -423,6 +423,43 @@ static napi_value js_read_sample_rgba8(napi_env env, napi_callback_info info)
     return ta;
 }
 
+/* pinHost(typedArray) / unpinHost(typedArray): page-lock the array's memory; readSampleRgba8Into(h, k, typedArray) then reads
+ * frame k straight into it (the caller's frame buffer, reused frame after frame). */
+static napi_value js_pin_host(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    void *p; size_t n;
+    if (!get_bytes(env, argv[0], &p, &n)) { napi_throw_type_error(env, NULL, "pinHost: typed array expected"); return NULL; }
+    int rc = crt_pin_host(p, n);
+    if (rc != CRT_OK) return throw_crt(env, NULL, rc, "crt_pin_host");
+    return undefined(env);
+}
+
+static napi_value js_unpin_host(napi_env env, napi_callback_info info)
+{
+    ARGS(1)
+    void *p; size_t n;
+    if (!get_bytes(env, argv[0], &p, &n)) { napi_throw_type_error(env, NULL, "unpinHost: typed array expected"); return NULL; }
+    int rc = crt_unpin_host(p);
+    if (rc != CRT_OK) return throw_crt(env, NULL, rc, "crt_unpin_host");
+    return undefined(env);
+}
+
+static napi_value js_read_sample_rgba8_into(napi_env env, napi_callback_info info)
+{
+    ARGS(3)
+    crt_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    uint32_t t[4], smp;
+    void *p; size_t n;
+    NAPI_OK(env, napi_get_value_uint32(env, argv[1], &smp));
+    if (!get_bytes(env, argv[2], &p, &n)) { napi_throw_type_error(env, NULL, "readSampleRgba8Into: typed array expected"); return NULL; }
+    CRT_CHECK(env, ctx, "crt_tile", crt_tile(ctx, t));
+    if (n < (size_t)t[2] * t[3] * 4) { napi_throw_range_error(env, NULL, "readSampleRgba8Into: need tw*th*4 bytes"); return NULL; }
+    CRT_CHECK(env, ctx, "crt_read_sample_rgba8", crt_read_sample_rgba8(ctx, smp, (uint8_t *)p));
+    return undefined(env);
+}
+
 /* ------------------------------------------------------------------ multi-GPU (include/crt.h "Multi-GPU") and composition
  * The reference drives one GPUDevice (src/main.js:8-9); a Node host reaches the tile-partitioned configurations through
  * these: one process (worker) per GPU, the communicator id made by one of them and passed around by the parent
@@ -760,7 +797,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"traceAsync", js_trace_async}, {"syncAsync", js_sync_async},
         {"readRgba8Async", js_read_rgba8_async}, {"readAccumAsync", js_read_accum_async},
         {"readLatestRgba8", js_read_latest_rgba8}, {"latestSample", js_latest_sample}, {"readSampleRgba8", js_read_sample_rgba8},
-        {"readSampleRgba8Async", js_read_sample_rgba8_async},
+        {"readSampleRgba8Async", js_read_sample_rgba8_async}, {"readSampleRgba8Into", js_read_sample_rgba8_into},
+        {"pinHost", js_pin_host}, {"unpinHost", js_unpin_host},
         {"commUniqueId", js_comm_unique_id}, {"commInit", js_comm_init}, {"commPartition", js_comm_partition},
         {"commInfo", js_comm_info}, {"commDestroy", js_comm_destroy}, {"gather", js_gather},
         {"readFrameRgba8", js_read_frame_rgba8}, {"readFrameAccum", js_read_frame_accum}, {"imageSize", js_image_size},

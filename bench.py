@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--band", type=int, default=8, help="rows per interleaved band for N>1 (0 = contiguous strips)")
     ap.add_argument("--accel", default="bvh2", choices=["bvh2", "lbvh"],
                     help="tree builder: bvh2 = binned SAH on the host (default), lbvh = crt_build_accel(LBVH), all on the GPU")
+    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
+                    help="the strips' gather: torch = all_gather_into_tensor on torch-owned buffers (the harness); native = crt_comm_* / "
+                         "crt_gather, the RCCL all-gather issued by libcrt itself (what the Node host uses; the id travels through torch.distributed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="crt_set_option before the run (e.g. wf_pipes=1 for the single-pipe profile); noted in config")
@@ -113,17 +116,39 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
+    native = args.gather == "native"
+    if native:
+        # the communicator of the C ABI: rank 0 makes the RCCL id (ncclGetUniqueId inside libcrt), the others get it
+        ids = [Renderer.comm_unique_id(local=False) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        r.comm_init(ids[0], rank, world)
     r.upload(ps)
     for o in args.opt:
         k, v = o.split("=")
         r.set_option(k, int(v))
     sf = (HostStagedStripFrame if backend != "nccl" else StripFrame)(W, H, world, rank, dev, band=(args.band if world > 1 else 0))
-    sf.apply(r)
+    if native:
+        r.comm_partition(args.band if world > 1 else 0)          # rows, strip / gather / frame buffers: all inside libcrt
+    else:
+        sf.apply(r)
     t0 = time.time()
     r.build_accel(args.accel)
     t_build = time.time() - t0
-    # strips live in torch tensors (padded to equal size) so RCCL can gather them
-    r.bind_output(sf.accum.data_ptr(), sf.rgba.data_ptr())
+    if native:
+        class NativeFrame:
+            # the same surface as StripFrame, over crt_gather / crt_read_frame_*
+            local_rows = r.tile[3]
+
+            def gather(self, accum=True):
+                r.gather(rgba8=True, accum=accum)
+
+            def image(self):
+                return torch.from_numpy(r.read_frame_accum()).to(dev), torch.from_numpy(r.read_frame_rgba8()).to(dev)
+        sf = NativeFrame()
+    else:
+        # strips live in torch tensors (padded to equal size) so RCCL can gather them
+        r.bind_output(sf.accum.data_ptr(), sf.rgba.data_ptr())
 
     # A step = one frame() of args.spp samples + the path's one exchange step, the all_gather of the rgba8
     # strips (RCCL over xGMI; the accumulator stays on its GPU like the reference's and is gathered once at
@@ -171,7 +196,7 @@ def main():
     r.set_option("time_kernels", 0)
     total_ms = elapsed * 1e3
     sf.gather(accum=True)      # final readout of the f32 XYZ accumulator (outside the timed steps)
-    if full_check and world > 1 and rank == 0:
+    if full_check and (world > 1 or native) and rank == 0:
         acc_all, rgba_all = sf.image()
         ref = Renderer(local_rank)
         ref.upload(ps).build_accel(args.accel).frame((args.warmup + args.steps) * args.spp).sync()
@@ -267,7 +292,8 @@ def main():
                                    if args.scene == "atrium250k" else
                                    f"{args.scene}: {ntri} triangles, {W}x{H}, {args.spp} spp per step",
                        "partition": (f"rows dealt to {world} GPUs in bands of {args.band}" if world > 1 and args.band else f"{world} horizontal strip(s)")
-                                    + ", scene replicated, all_gather of the rgba8 strips per step",
+                                    + ", scene replicated, all_gather of the rgba8 strips per step"
+                                    + (" (crt_gather: RCCL issued by libcrt)" if native else " (torch.distributed all_gather_into_tensor)"),
                        "accel": ("binned-SAH BVH2 collapsed to 4-wide 64-byte quantised nodes (host build %.2f s; crt_build_accel(LBVH) builds on the GPU in milliseconds)" % t_build)
                                 if args.accel == "bvh2" else
                                 ("LBVH built, collapsed to 4-wide 64-byte quantised nodes and leaf-ordered on the GPU (crt_build_accel(LBVH): %.3f s)" % t_build),

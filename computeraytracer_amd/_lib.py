@@ -37,6 +37,8 @@ SIGNATURES = {
     "crt_write_accum": (C.c_int, [_P, _P, C.c_uint32]),
     "crt_read_latest_rgba8": (C.c_int, [_P, _P, _P]),
     "crt_latest_sample": (C.c_int, [_P, _P]),
+    "crt_pin_host": (C.c_int, [_P, C.c_size_t]),
+    "crt_unpin_host": (C.c_int, [_P]),
     "crt_read_sample_rgba8": (C.c_int, [_P, C.c_uint32, _P]),
     "crt_device_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "crt_bind_output": (C.c_int, [_P, _P, _P]),

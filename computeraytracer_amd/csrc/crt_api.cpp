@@ -130,6 +130,8 @@ struct crt_ctx {
     DevBuf<uchar4> d_rgba;
     DevBuf<uchar4> d_frames;        // option "frame_ring" = F: the rgba8 frame of each of the last F samples (tile-sized each)
     uint32_t frame_ring = 0;
+    std::vector<uint8_t> frame_batch;   // per ring slot: the batch id whose resolve pass wrote that frame (its ev_resolved orders a read)
+    hipStream_t read_stream = nullptr;  // readbacks from the ring: they wait for the frame's own resolve pass, not for the retirement work queued behind it
     uint32_t resolved_upto = 0;     // samples whose resolve pass has been enqueued on the context's stream (frames <= this are in the ring / the framebuffer in stream order)
     float4 *accum_bound = nullptr;
     uchar4 *rgba_bound = nullptr;
@@ -229,6 +231,8 @@ int alloc_tile(crt_ctx *c)
     HIPCHK(c, c->d_accum.alloc(n));
     HIPCHK(c, c->d_rgba.alloc(n));
     if (c->frame_ring) HIPCHK(c, c->d_frames.alloc(n * c->frame_ring)); else c->d_frames.release();
+    c->frame_batch.assign(c->frame_ring, 0);
+    if (c->frame_ring && !c->read_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
     return CRT_OK;
 }
 
@@ -237,6 +241,8 @@ int alloc_frames(crt_ctx *c)
 {
     const size_t n = (size_t)c->tw * c->th;
     if (c->frame_ring) HIPCHK(c, c->d_frames.alloc(n * c->frame_ring)); else c->d_frames.release();
+    c->frame_batch.assign(c->frame_ring, 0);
+    if (c->frame_ring && !c->read_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
     return CRT_OK;
 }
 
@@ -698,6 +704,8 @@ int wf_resolve_batch(crt_ctx *c, const WfBatch &b)
     R.frames = c->d_frames.p; R.frame_ring = c->frame_ring;
     HIPCHK(c, wf_launch_resolve(R, b.last_sample, c->stream));
     c->resolved_upto = b.last_sample;
+    if (c->frame_ring && c->frame_batch.size() == c->frame_ring)
+        for (uint32_t k = 0; k < b.n && k < c->frame_ring; k++) c->frame_batch[(b.last_sample - 1u - k) % c->frame_ring] = (uint8_t)b.id;
     HIPCHK(c, hipEventRecord(c->ev_resolved[b.id], c->stream));    // the id's queue, staging buffer and side pools are free after this
     r.resolved_recorded[b.id] = true;
     c->last_launches++;
@@ -1010,6 +1018,31 @@ bool wf_has_room(crt_ctx *c)
     return hipEventQuery(c->ev_resolved[id]) == hipSuccess;
 }
 
+// ---- Invariants of the driver (publish / pump / retire), kept next to the loop that depends on all of them ----
+//  I1  Iteration numbers of a pipe never repeat: a run starts 2 * kStatusRing behind the previous run's last number, so a
+//      late status write of an earlier run can never match the `it_end` a poll is waiting for.
+//  I2  Iteration i's status record is written by the FIRST wave of shade launch i + 1 (slot i % kStatusRing) and is
+//      pending while it_confirmed <= i < it; wf_enqueue refuses to run more than kStatusRing - 1 ahead of it_confirmed, so
+//      a slot is never rewritten before it has been read.  A poll accepts a slot only when its it_end is exactly
+//      it_confirmed + 1 (acquire load of the word the device stores last, behind a system-scope fence).
+//  I3  What a status says about a queue is FINAL for that launch: since round 3 nothing takes work inside a shade launch
+//      (k_wf_gen does, between the shade launches), so cursors (`left`, `consumed`) and alive counts of one record are
+//      one consistent cut -- taken after gen(i) has completed and before gen(i + 1) starts.
+//  I4  A batch's statuses count only from launches enqueued after the HOST has seen its queue reset complete
+//      (wf_check_ready sets from_it then; earlier launches may have read the id's previous extent).  Until then the
+//      queue is not listed (wf_set_queues) and no launch can take its work.
+//  I5  `dry[id]` of a pipe is monotone within a batch, and once a pipe has seen the queue dry no path of the batch can
+//      start in that pipe any more (cursors only grow): alive[id] of that record bounds the pipe's paths from then on.
+//      wf_retire evicts only when EVERY pipe's record says dry and the counts fit the side pools (k_wf_finish reports,
+//      through WfCtl::dropped, if they did not).
+//  I6  Batches resolve in publication order (the accumulator is summed in sample order); a batch id is reused only after
+//      ev_resolved[id] of its previous user has COMPLETED (wf_has_room), and the reset of the id's queue additionally waits,
+//      on the device, for launches that still list the old queue (listed_until) and for that resolve.
+//  I7  Staging buffers, pool arrays and lists are never reallocated while r.live (wf_trace_batch flushes first).
+//  I8  Every loop below makes progress or blocks on something the device will complete: a launch is always enqueued
+//      behind the status being waited for (the record is written by the NEXT launch), back-pressure waits are on events
+//      recorded behind enqueued work, and a wall-clock watchdog turns a violated assumption into CRT_EDEVICE + state dump.
+//
 // Feed the pool: enqueue the iterations the published work needs (see the head of this section).  for_room = false:
 // return once they are enqueued (the call does not wait for its work); for_room = true: keep feeding and reading
 // statuses until there is room for another batch (back-pressure of a caller that publishes faster than the pool works).
@@ -1080,6 +1113,26 @@ int wf_pump(crt_ctx *c, bool for_room)
         if (wf_debug()) fprintf(stderr, "[pump %8.2f] enqueued %u on pipe %d in %.3f ms (in flight %u %u, need %.0f, open %zu)\n", wf_now_ms(), iters, p, wf_now_ms() - t0, fl[0], fl[r.K - 1], need, r.open.size());
     }
     return fail(c, CRT_EDEVICE, "wavefront driver: pump did not converge");
+}
+
+// A cheap turn of the driver for calls that publish nothing themselves (a small call that is only noted, a query of the
+// latest frame): read the statuses that have arrived, and where a retirement decision waits for a pipe's next shade launch
+// (evict_next), give it one -- so that batches keep retiring (finish + resolve) while a display loop runs ahead of them.
+int wf_tick(crt_ctx *c)
+{
+    if (!c->run || !c->run->live || c->in_publish) return CRT_OK;
+    WfRun &r = *c->run;
+    int rc = wf_poll_all(c);
+    if (rc) return rc;
+    for (int p = 0; p < r.K; p++) {
+        WfPipe &pp = r.pipes[p];
+        if (pp.evict_next == 0 || pp.done) continue;
+        if (wf_in_flight(c, p) >= (uint32_t)std::max(c->wf_ahead, c->wf_chunk + 1)) continue;
+        if (pp.it - pp.it_confirmed + 1u >= (uint32_t)kStatusRing - 1u) continue;
+        rc = wf_enqueue(c, p, 1);
+        if (rc) return rc;
+    }
+    return CRT_OK;
 }
 
 // Run everything in the pool to its end and resolve every batch.
@@ -1555,6 +1608,7 @@ void crt_destroy(crt_ctx *c)
         if (c->ev_pub[b]) (void)hipEventDestroy(c->ev_pub[b]);
     }
     if (c->pub_stream) (void)hipStreamDestroy(c->pub_stream);
+    if (c->read_stream) { (void)hipStreamSynchronize(c->read_stream); (void)hipStreamDestroy(c->read_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->h_dropped) (void)hipHostFree(c->h_dropped);
 
@@ -1729,7 +1783,8 @@ int crt_trace(crt_ctx *c, uint32_t n_samples)
     uint32_t left = n_samples;
     if (c->pipeline == 1 && c->accel_mode == CRT_ACCEL_BVH2) {
         c->sample += n_samples; c->pending += n_samples;
-        int rc = wf_publish_pending(c, false);
+        int rc = wf_tick(c);
+        if (rc == CRT_OK) rc = wf_publish_pending(c, false);
         if (rc) return rc;                                       // (what was not published is not part of the frame)
     } else {
         { int rc_ = wf_flush(c); if (rc_) return rc_; }
@@ -1817,10 +1872,28 @@ static int wf_wait_sample(crt_ctx *c, uint32_t sample)
     return CRT_OK;
 }
 
+// Page-lock caller memory so that readbacks into it run at PCIe speed (an 8 MB 1080p frame: 0.15 ms instead of 1.5-2.5 ms
+// through the runtime's staging of pageable memory) -- what a display loop that shows every frame wants for its frame buffer.
+int crt_pin_host(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return CRT_EINVAL;
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, CRT_EDEVICE, "crt_pin_host: %s", hipGetErrorString(e)); }
+    return CRT_OK;
+}
+
+int crt_unpin_host(void *ptr)
+{
+    if (!ptr) return CRT_EINVAL;
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, CRT_EDEVICE, "crt_unpin_host: %s", hipGetErrorString(e)); }
+    return CRT_OK;
+}
+
 int crt_latest_sample(crt_ctx *c, uint32_t *out)
 {
     if (!c || !out) return CRT_EINVAL;
-    if (c->run && c->run->live) { HIPCHK(c, hipSetDevice(c->device)); int rc = wf_poll_all(c); if (rc) return rc; }   // (retire what has finished meanwhile)
+    if (c->run && c->run->live) { HIPCHK(c, hipSetDevice(c->device)); int rc = wf_tick(c); if (rc) return rc; }   // (retire what has finished meanwhile)
     *out = c->resolved_upto;
     return CRT_OK;
 }
@@ -1830,7 +1903,7 @@ int crt_read_latest_rgba8(crt_ctx *c, uint8_t *out, uint32_t *sample)
     if (!c || !out) return CRT_EINVAL;
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_latest_rgba8: no scene");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->run && c->run->live) { int rc = wf_poll_all(c); if (rc) return rc; }
+    if (c->run && c->run->live) { int rc = wf_tick(c); if (rc) return rc; }
     // No flush: in stream order the framebuffer holds the complete frame of the newest batch whose resolve pass has been
     // enqueued (crt_trace's contract for bound outputs); the copy is queued behind it.
     const uint32_t s = c->resolved_upto;
@@ -1851,10 +1924,15 @@ int crt_read_sample_rgba8(crt_ctx *c, uint32_t sample, uint8_t *out)
     if (c->pipeline != 1 || c->accel_mode != CRT_ACCEL_BVH2) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: frames are kept by the wavefront pipeline only");
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = wf_wait_sample(c, sample); if (rc) return rc; }
+    // The copy waits for the resolve pass that wrote this frame (the batch id's event: a later re-recording of it only
+    // orders more), on a stream of its own -- not for the finish / resolve work of later batches queued on the context's.
     const size_t n = (size_t)c->tw * c->th;
-    if (n) HIPCHK(c, hipMemcpyAsync(out, c->d_frames.p + (size_t)((sample - 1u) % c->frame_ring) * n, n * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return wf_check_dropped(c);
+    const uint32_t slot = (sample - 1u) % c->frame_ring;
+    if (c->run && c->run->resolved_recorded[c->frame_batch[slot]]) HIPCHK(c, hipStreamWaitEvent(c->read_stream, c->ev_resolved[c->frame_batch[slot]], 0));
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(c, hipMemcpyAsync(out, c->d_frames.p + (size_t)slot * n, n * sizeof(uchar4), hipMemcpyDeviceToHost, c->read_stream));
+    HIPCHK(c, hipStreamSynchronize(c->read_stream));
+    return CRT_OK;
 }
 
 int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)

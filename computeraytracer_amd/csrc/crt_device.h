@@ -80,6 +80,7 @@ struct TraceParams {
 //   list[parity][class]                   slots with an active ray this iteration (ballot/popc compacted)
 //   staging[b] (xyz, -) per (sample, pixel)  finished samples of the batch with id b, summed in sample order by k_wf_resolve
 constexpr uint32_t kWfAlive = 1u, kWfDying = 2u, kWfShadow = 4u, kWfSpecular = 8u, kWfInTrans = 16u;
+constexpr uint32_t kWfNanRay = 1u << 31;   // the slot's (camera) ray is non-finite and has not been traced: the next shade step resolves it with the reference loop
 constexpr uint32_t kWfHasRad = 1u << 30;   // radiance[slot] holds the path's radiance (else it is still zero: nothing was ever stored)
 // ray-list entries: the slot, and on shadow-list entries a mark "this slot also listed an extension ray"
 constexpr uint32_t kWfListSlot = 0x7FFFFFFFu, kWfListAlsoExt = 0x80000000u;

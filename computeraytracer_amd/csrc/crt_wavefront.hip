@@ -288,9 +288,14 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     bool sh_primary = false;                          // ray class: shadow ray of a camera-ray hit
     bool finished = false, rad_dirty = false;
     f3 out_sd = f3{0, 0, 0}; float out_tl = 0.0f; uint32_t out_lindex = 0, out_lslot = 0;   // the shadow ray, if one is emitted
+    // A non-finite camera ray of k_wf_gen (the camera itself is not finite) has not been traced: this step only re-emits it,
+    // and the write-back below decides it with the reference loop like any other non-finite ray (shade_store) -- the path
+    // is shaded one iteration later.  (No second call site of that loop here: it would cost the kernel 10 registers.)
+    const bool nan_ray = alive && (R.flags & kWfNanRay) != 0u;
+    if (nan_ray) R.flags &= ~kWfNanRay;
     // the hit primitive's whole record, also in one batch (valid only for an alive slot with a hit)
     const uint32_t h_slot = f_bits(h.y);
-    const bool has_hit = alive && !(R.flags & kWfDying) && h_slot != kNoHit;
+    const bool has_hit = alive && !nan_ray && !(R.flags & kWfDying) && h_slot != kNoHit;
     float4 hA = float4{0, 0, 0, 0}, hB = hA, hC = hA, hD = hA;
     if (has_hit) { hA = S.prim[3 * (size_t)h_slot + 0]; hB = S.prim[3 * (size_t)h_slot + 1]; hC = S.prim[3 * (size_t)h_slot + 2]; hD = S.primD[h_slot]; }
     CRT_PROBE(tp, 2)
@@ -314,6 +319,8 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
         }
         if (R.flags & kWfDying) {
             finished = true;                                     // roulette ended it last iteration (:284-287)
+        } else if (nan_ray) {
+            emit_ext = true;                                     // (resolved by the write-back; counted as a ray when it was generated)
         } else {
             // 2. the extension ray's closest hit (:135-146)
             const uint32_t b_slot = h_slot;
@@ -719,7 +726,7 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
     //      segments of consecutive work items -- the wave's own shard of the listed queues, oldest first, or one other
     //      shard when all of its own are dry.  (Ranges, totals and steps are multiples of 64.)  What finds no work stays dead.
     uint32_t seg_q[2] = {0, 0}, seg_n[2] = {0, 0}, nseg = 0, want = mine;
-    unsigned long long seg_w[2] = {0, 0};
+    uint32_t seg_w[2] = {0, 0};                                          // (work ids fit 32 bits: wf_batch_cap)
     for (uint32_t si = 0; si < P.seg_n && want > 0u && nseg < 2u; si++) {
         const uint32_t sg = P.seg_order[si];
         WfWorkQ *wq = P.wq + sg;
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= size) continue;
         const uint32_t got = min(want, (size - base) / 64u);
-        seg_q[nseg] = sg; seg_w[nseg] = lo + base; seg_n[nseg] = got; nseg++;
+        seg_q[nseg] = sg; seg_w[nseg] = (uint32_t)lo + base; seg_n[nseg] = got; nseg++;
         want -= got;
     }
     for (uint32_t si = 0; si < P.seg_n && nseg == 0u; si++) {            // every shard of every listed queue, one try each
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
         const uint32_t size_s = (uint32_t)__shfl((int)size_l, (int)s_pick, 64);
         if (base >= size_s) continue;
         const uint32_t got = min(want, (size_s - base) / 64u);
-        seg_q[0] = sg; seg_w[0] = (unsigned long long)s_pick * wps + base; seg_n[0] = got; nseg = 1;
+        seg_q[0] = sg; seg_w[0] = s_pick * wps + base; seg_n[0] = got; nseg = 1;
         want -= got;
     }
     const uint32_t total = seg_n[0] + seg_n[1];
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
         for (uint32_t g = 0; g < 2u; g++) {
             n_valid[g] = 0;
             for (uint32_t k = 0; k < seg_n[g]; k++) {
-                const uint32_t tile = (uint32_t)((seg_w[g] + 64ull * k) % P.npix_padded) >> 6;
+                const uint32_t tile = ((seg_w[g] + 64u * k) % P.npix_padded) >> 6;
                 const uint32_t lx = (tile % P.tiles_x) * 8u + (lane & 7u), ly = (tile / P.tiles_x) * 8u + (lane >> 3);
                 n_valid[g] += (uint32_t)__popcll(__ballot(lx < P.tw && ly < P.th));
             }
@@ -790,8 +797,8 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
     for (uint32_t k = 0; k < total; k++) {
         const uint32_t g = k < seg_n[0] ? 0u : 1u, kk = g ? k - seg_n[0] : k;
         const uint32_t sg = seg_q[g];
-        const unsigned long long w0 = seg_w[g] + 64ull * kk;
-        const uint32_t sample_off = (uint32_t)(w0 / P.npix_padded), pp0 = (uint32_t)(w0 % P.npix_padded);
+        const uint32_t w0 = seg_w[g] + 64u * kk;
+        const uint32_t sample_off = w0 / P.npix_padded, pp0 = w0 % P.npix_padded;
         const uint32_t tile = pp0 >> 6;
         const uint32_t lx = (tile % P.tiles_x) * 8u + (lane & 7u), ly = (tile / P.tiles_x) * 8u + (lane >> 3);
         const bool valid = lx < P.tw && ly < P.th;
@@ -813,17 +820,17 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
             d = normalize(((llc + hor * fs) + ver * ft) - eye);
             const float ul = rnd(rng);
             const uint32_t lambda = (uint32_t)(301.0f * ul);                                  // :317-319
-            const uint32_t flags = kWfAlive | (lambda << kWfLambdaShift) | (sg << kWfBatchShift);
+            const bool nan_ray = !finite3(eye) || !finite3(d);
+            const uint32_t flags = kWfAlive | (lambda << kWfLambdaShift) | (sg << kWfBatchShift) | (nan_ray ? kWfNanRay : 0u);
             stnt(&P.ray_o[slot], float4{eye.x, eye.y, eye.z, bits_f(0xFFFFFFFFu)});
             stnt(&P.ray_d[slot], float4{d.x, d.y, d.z, bits_f(0u)});
             stnt(&P.beta[slot], float4{1.0f, 1.0f, 1.0f, 1.0f});
             stnt(&P.rng[slot], uint4{rng.x, rng.y, rng.z, rng.w});
-            stnt(&P.misc[slot], uint4{(uint32_t)w0 + lane, flags, f_bits(1.0f), f_bits(1.0f)});   // work, flags, last_pdf, etaScale
-            // (a camera ray is finite by construction unless the camera itself is not: then it is resolved like any other)
-            if (!finite3(eye) || !finite3(d)) {
-                P.hit[slot] = resolve_nonfinite(S.prim, S.primD, S.slot_of_index, S.nprim, S.hit_pad, eye.x, eye.y, eye.z, d.x, d.y, d.z, 0xFFFFFFFFu);
-                resolved = 1u;
-            }
+            stnt(&P.misc[slot], uint4{w0 + lane, flags, f_bits(1.0f), f_bits(1.0f)});   // work, flags, last_pdf, etaScale
+            // (a camera ray is finite unless the camera itself is not.  Such a ray is decided by the reference loop in its own
+            // order like any other non-finite ray -- by the NEXT shade step (kWfNanRay): a call to that loop in this kernel would
+            // cost it half its occupancy in registers, and the kernel sits between the shade and the traversal launch of its pipe)
+            if (!finite3(eye) || !finite3(d)) resolved = 1u;
         }
         if (!have_b0) { b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); have_b0 = true; }   // (its round trip ran under the first set-up)
         if (valid) {
@@ -1262,6 +1269,9 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
 #ifndef CRT_WF_PICK_AT
 #define CRT_WF_PICK_AT 8
 #endif
+#ifndef CRT_WF_PKFMA
+#define CRT_WF_PKFMA 0
+#endif
 #ifndef CRT_WF_LEAF2_AT
 #define CRT_WF_LEAF2_AT 32
 #endif
@@ -1546,6 +1556,28 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                     const uint32_t nxa = gx ? Q1.z : Q0.x, nxb = gx ? Q1.w : Q0.y, fxa = gx ? Q0.x : Q1.z, fxb = gx ? Q0.y : Q1.w;
                     const uint32_t nya = gy ? Q2.x : Q0.z, nyb = gy ? Q2.y : Q0.w, fya = gy ? Q0.z : Q2.x, fyb = gy ? Q0.w : Q2.y;
                     const uint32_t nza = gz ? Q2.z : Q1.x, nzb = gz ? Q2.w : Q1.y, fza = gz ? Q1.x : Q2.z, fzb = gz ? Q1.y : Q2.w;
+#if CRT_WF_PKFMA
+                    // the 24 plane distances as 12 packed fmas (v_pk_fma_f32: children 0/1 and 2/3 of a plane share a dword).  Measured 4 %
+                    // SLOWER on the step (profiles/r03_ab_pkfma.txt: the packed form pairs registers and spills in the set-up): off.
+                    {
+                        const v2f ix = v2f{id.x, id.x}, iy = v2f{id.y, id.y}, iz = v2f{id.z, id.z};
+                        const v2f ox = v2f{oid.x, oid.x}, oy = v2f{oid.y, oid.y}, oz = v2f{oid.z, oid.z};
+#define CRT_PK(Q, I, O) __builtin_elementwise_fma(v2f{(float)((Q) & 0xFFFFu), (float)((Q) >> 16)}, I, O)
+                        const v2f tnx_a = CRT_PK(nxa, ix, ox), tnx_b = CRT_PK(nxb, ix, ox), tfx_a = CRT_PK(fxa, ix, ox), tfx_b = CRT_PK(fxb, ix, ox);
+                        const v2f tny_a = CRT_PK(nya, iy, oy), tny_b = CRT_PK(nyb, iy, oy), tfy_a = CRT_PK(fya, iy, oy), tfy_b = CRT_PK(fyb, iy, oy);
+                        const v2f tnz_a = CRT_PK(nza, iz, oz), tnz_b = CRT_PK(nzb, iz, oz), tfz_a = CRT_PK(fza, iz, oz), tfz_b = CRT_PK(fzb, iz, oz);
+#undef CRT_PK
+#define CRT_QK(K, NX, NY, NZ, FX, FY, FZ) { \
+                            const float tn_ = __builtin_fmaxf(__builtin_fmaxf(NX, NY), __builtin_fmaxf(NZ, t_min)); \
+                            const float tf_ = __builtin_fminf(__builtin_fminf(FX, FY), __builtin_fminf(FZ, t_max)); \
+                            K = (tn_ <= tf_ * 1.0000005f) ? tn_ : 3.0e38f; }
+                        CRT_QK(k0, tnx_a.x, tny_a.x, tnz_a.x, tfx_a.x, tfy_a.x, tfz_a.x)
+                        CRT_QK(k1, tnx_a.y, tny_a.y, tnz_a.y, tfx_a.y, tfy_a.y, tfz_a.y)
+                        CRT_QK(k2, tnx_b.x, tny_b.x, tnz_b.x, tfx_b.x, tfy_b.x, tfz_b.x)
+                        CRT_QK(k3, tnx_b.y, tny_b.y, tnz_b.y, tfx_b.y, tfy_b.y, tfz_b.y)
+#undef CRT_QK
+                    }
+#else
 #define CRT_QBOX(K, NXQ, NYQ, NZQ, FXQ, FYQ, FZQ) { \
                         const float tn_ = __builtin_fmaxf(__builtin_fmaxf(fma_((float)(NXQ), id.x, oid.x), fma_((float)(NYQ), id.y, oid.y)), \
                                                           __builtin_fmaxf(fma_((float)(NZQ), id.z, oid.z), t_min)); \
@@ -1557,6 +1589,7 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                     CRT_QBOX(k2, nxb & 0xFFFFu, nyb & 0xFFFFu, nzb & 0xFFFFu, fxb & 0xFFFFu, fyb & 0xFFFFu, fzb & 0xFFFFu)
                     CRT_QBOX(k3, nxb >> 16, nyb >> 16, nzb >> 16, fxb >> 16, fyb >> 16, fzb >> 16)
 #undef CRT_QBOX
+#endif
                     r0 = (int)Q3.x; r1 = (int)Q3.y; r2 = (int)Q3.z; r3 = (int)Q3.w;
                     if (COUNT) c_nodes += 4;
                     // sort the four (key, ref) pairs by entry distance: 5 compare-exchanges

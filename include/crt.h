@@ -152,6 +152,10 @@ int crt_read_rgba8(crt_ctx *ctx, uint8_t *out);
  *                           that requests frames a cohort ahead of the one it shows (host/display_loop.js) sees every frame
  *                           index exactly once while small calls are still merged into cohorts. */
 int crt_read_latest_rgba8(crt_ctx *ctx, uint8_t *out, uint32_t *sample);
+/* Page-lock / release caller memory (hipHostRegister): readbacks into pinned memory run at PCIe speed -- for the frame
+ * buffer a display loop reads every frame into.  No context needed; errors are reported through crt_last_error(NULL). */
+int crt_pin_host(void *ptr, size_t bytes);
+int crt_unpin_host(void *ptr);
 int crt_latest_sample(crt_ctx *ctx, uint32_t *out);
 int crt_read_sample_rgba8(crt_ctx *ctx, uint32_t sample, uint8_t *out);
 /* Restore an accumulator + sample count (checkpoint/resume). */

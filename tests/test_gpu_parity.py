@@ -745,6 +745,29 @@ def test_non_finite_shadow_rays_follow_the_reference_loop(renderer, orc, light_l
         renderer.set_option("pipeline", 1)
 
 
+def test_non_finite_camera_follows_the_reference_loop(renderer, orc):
+    """A camera whose eye is at infinity: every camera ray is non-finite, and the reference's reject-form tests let a
+    NaN pass every patch and sphere (:546,557,566,605,609), so `intersect` returns the last primitive of the array --
+    decided by the reference loop itself in every pipeline form (k_wf_gen flags such rays, the next shade step's
+    write-back resolves them)."""
+    from computeraytracer_amd import cornell, scene as S
+    c = cornell(48, 40)
+    cam = c.camera.copy()
+    cam[0] = np.inf
+    ps = S.PackedScene(c.primitives, c.lights, cam, c.spectra, c.cie)
+    acc_o, rgba_o, _ = orc.Scene.from_packed(ps).render(3)
+    nan_o = np.isnan(acc_o[..., :3]).any(-1)
+    try:
+        for pipeline, mode in [(1, "bvh2"), (0, "bvh2"), (1, "none")]:
+            renderer.set_option("pipeline", pipeline)
+            acc, rgba = render(renderer, ps, 3, mode)
+            assert np.array_equal(np.isnan(acc[..., :3]).any(-1), nan_o), (pipeline, mode)
+            assert np.array_equal(bits(acc[~nan_o])[..., :3], bits(acc_o[~nan_o])[..., :3]), (pipeline, mode)
+            assert np.array_equal(rgba, rgba_o), (pipeline, mode)
+    finally:
+        renderer.set_option("pipeline", 1)
+
+
 def test_out_of_memory_is_reported_and_the_context_recovers(orc):
     """A failed device allocation (injected: option debug_fail_alloc = k fails the k-th one) gives CRT_ENOMEM, never a
     launch on a null pointer; the same context renders correctly afterwards."""

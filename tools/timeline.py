@@ -3,8 +3,8 @@ nobody tracing, one traversal kernel running, two; what runs beside them.  Usage
 import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 ev = []
-short = lambda n: ('trace' if 'k_wf_trace<false' in n else 'shade' if 'k_wf_shade<false' in n else 'finish' if 'k_wf_finish<false' in n
-                   else 'resolve' if 'k_wf_resolve' in n else None)
+short = lambda n: ('trace' if ('k_wf_trace<false' in n or 'k_wf_trace2<false' in n) else 'shade' if 'k_wf_shade<false' in n else 'gen' if 'k_wf_gen<false' in n
+                   else 'finish' if 'k_wf_finish<false' in n else 'resolve' if 'k_wf_resolve' in n else None)
 ks = [(short(r['Kernel_Name']), int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id']) for r in rows]
 ks = [k for k in ks if k[0]]
 # the timed region: the longest run of launches without a pause of more than 5 ms; its middle 80 %
@@ -24,7 +24,7 @@ for n, s, e, q in ks:
 pts.sort()
 state = collections.Counter(); dur = collections.Counter(); last = lo
 for t, n, d in pts:
-    key = 'trace=%d shade=%d other=%d' % (state['trace'], state['shade'], state['finish'] + state['resolve'])
+    key = 'trace=%d shade=%d gen=%d other=%d' % (state['trace'], state['shade'], state['gen'], state['finish'] + state['resolve'])
     dur[key] += t - last; last = t
     state[n] += d
 tot = sum(dur.values())
@@ -37,7 +37,7 @@ for n, v in per.items(): print('%-8s launches %5d  avg %.3f ms  sum %.1f ms  (sp
 gaps = collections.defaultdict(list)
 byq = collections.defaultdict(list)
 for n, s, e, q in ks:
-    if n in ('trace', 'shade') and s >= lo and e <= hi: byq[q].append((s, e, n))
+    if n in ('trace', 'shade', 'gen') and s >= lo and e <= hi: byq[q].append((s, e, n))
 for q, v in byq.items():
     v.sort()
     for a, b in zip(v, v[1:]): gaps[q + ':' + a[2] + '->' + b[2]].append((b[0] - a[1]) / 1e3)
