@@ -237,6 +237,19 @@ def main():
         r.set_option("pipeline", 1)
         canon = (32.0 * c2["nodes"] + 48.0 * c2["prims"] + 16.0 * c2["hits"] + 36.0 * c2["paths"]) / max(c2["rays"], 1)
         canon_counts = (c2["nodes"] / max(c2["rays"], 1), c2["prims"] / max(c2["rays"], 1))
+    # The dominant kernel with the GPU to itself (one pipe, nothing beside it): two more untimed steps.  In the product two pipes
+    # overlap a traversal launch with the other pipe's shade / generate launches, so the kernel's summed launch durations
+    # (roofline.frac) measure how the pipes share the GPU as much as the kernel; this is the kernel alone.
+    alone = None
+    if rank == 0 and world == 1 and os.environ.get("CRT_BENCH_NOTK") != "1" and not any(o.startswith("wf_pipes=") for o in args.opt):
+        r.set_option("wf_pipes", 1).set_option("wf_waves_per_cu", 20)
+        r.reset()
+        r.frame(args.spp).sync()
+        r.set_option("time_kernels", 80 * args.spp + 4096)
+        r.frame(args.spp).frame(args.spp).sync()
+        a_ms, a_n = r.last_kernel_ms()
+        r.set_option("time_kernels", 0).set_option("wf_pipes", 2).set_option("wf_waves_per_cu", 0)
+        alone = (a_ms, a_n, 2)
     cnt = torch.tensor([c["rays"], c["nodes"], c["prims"], c["hits"], c["paths"], c["shadow"], c["walked"]], dtype=torch.float64, device=dev)
     mine = cnt.clone()
     if world > 1:
@@ -318,6 +331,12 @@ def main():
                          "node_bytes_per_box": st["bytes_per_box"], "node_width": st["width"],
                          "boxes_per_ray": round(m_nodes / max(m_rays, 1), 2), "prims_per_ray": round(m_prims / max(m_rays, 1), 2),
                          "kernel_share_of_pass": round(kernel_ms / max(total_ms, 1e-9), 3),
+                         "kernel_alone": (None if not alone else {
+                             "what": "the same kernel with the GPU to itself: one pipe (no shade / generate launch beside it), 20 traversal waves per CU, "
+                                     "two untimed steps after the timed region; algorithmic bytes per step as in the timed steps",
+                             "launches": alone[1], "avg_launch_ms": round(alone[0] / max(alone[1], 1), 4),
+                             "achieved": round(alg_bytes / args.steps * alone[2] / (alone[0] * 1e-3) / 1e9, 2),
+                             "frac": round(alg_bytes / args.steps * alone[2] / (alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}),
                          "note": "two half-pool pipes run on two streams, so a traversal launch and the other pipe's k_wf_shade / k_wf_gen overlap: "
                                  "summed launch durations exceed the wall time of the pass; whole_pass_* = bytes / wall time",
                          "whole_pass_GBs": round(whole_pass, 1), "whole_pass_frac": round(whole_pass / HBM_PEAK_GBS, 5),

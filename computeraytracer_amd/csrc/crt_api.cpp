@@ -164,6 +164,7 @@ struct crt_ctx {
     int wf_pipes = 2;
     int wf_defer = 1;               // 1: crt_trace returns with its batch in flight; its paths finish under the next batches (or at crt_sync)
     int wf_tail_walk = 1;           // shade walks the ray lists once few paths are left
+    int wf_gen_blocks = 128;        // k_wf_gen: waves per shard (64 shards)
     int wf_trace_form = 2;          // traversal kernel: 2 = k_wf_trace2 (ray ring + primitive tasks), 1 = k_wf_trace
     int wf_chunk = 1;               // iterations per status record at most
     int wf_ahead = 3;               // iterations in flight per pipe before the pump waits for a status
@@ -1410,7 +1411,7 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             W.dead = c->w_dead.p + (g.list_per_pipe / 8) * (size_t)p;
             W.rearm = 0;
             // k_wf_gen: waves per shard (each takes every gen_blocks-th chunk of 64 dead slots of its shard's list)
-            W.gen_blocks = std::max(1u, std::min(128u, g.list_cap / 64u));
+            W.gen_blocks = std::max(1u, std::min((uint32_t)c->wf_gen_blocks, g.list_cap / 64u));
             W.recA = c->w_recA.p + g.list_per_pipe * (size_t)p; W.recB = c->w_recB.p + g.list_per_pipe * (size_t)p;
             W.recC = c->w_recC.p + g.list_per_pipe * (size_t)p;
             for (uint32_t b = 0; b < kWfRing; b++) {
@@ -2097,6 +2098,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
         if (c->have_scene) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return alloc_frames(c); }
         return CRT_OK;
     }
+    if (!std::strcmp(name, "wf_gen_blocks")) { c->wf_gen_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_trace_form")) { c->wf_trace_form = value == 1 ? 1 : 2; return CRT_OK; }
     if (!std::strcmp(name, "wf_pipes")) { c->wf_pipes = (int)std::min<int64_t>(crt_ctx::kMaxPipes, std::max<int64_t>(1, value)); return CRT_OK; }
     if (!std::strcmp(name, "wf_pool")) { c->wf_pool = (uint32_t)std::max<int64_t>(0, value); return CRT_OK; }

@@ -84,6 +84,8 @@ __device__ __forceinline__ void stnt(float4 *p, float4 v) { __builtin_nontempora
 __device__ __forceinline__ void stnt(uint4 *p, uint4 v) { __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p); }
 __device__ __forceinline__ void stnt(float2 *p, float2 v) { __builtin_nontemporal_store(v2f{v.x, v.y}, (v2f *)p); }
 __device__ __forceinline__ void stnt(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stnt(uint2 *p, uint2 v) { __builtin_nontemporal_store(v2u{v.x, v.y}, (v2u *)p); }
 #else
 template <class T> __device__ __forceinline__ T ldnt(const T *p) { return *p; }
 template <class T> __device__ __forceinline__ void stnt(T *p, T v) { *p = v; }
@@ -465,10 +467,12 @@ __device__ __forceinline__ uint32_t shade_store(const WfParams &P, uint32_t slot
     PathRegs &R = so.R;
     uint32_t resolved = 0u;
     if (in_pool) {
+        // ray_o, beta and misc are written for EVERY slot: a dead slot gets what a fresh path starts with (the eye, no exclusion,
+        // throughput 1, last_bounce_pdf = etaScale = 1) here, in the launch's coalesced streams, so that k_wf_gen -- whose
+        // stores go to scattered slots, 16 bytes at a time: 2.5 x their size in HBM writes -- only writes what depends on the pixel.
+        const float4 vo = so.alive ? float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)} : float4{S.cam[9], S.cam[10], S.cam[11], bits_f(0xFFFFFFFFu)};
+        stnt(&P.ray_o[slot], vo);
         if (so.alive) {
-#ifndef CRT_WHATIF_NO_RAYW           /* sensitivity probe (wrong image): the slot's ray arrays not written */
-            stnt(&P.ray_o[slot], float4{R.ray_o.x, R.ray_o.y, R.ray_o.z, bits_f(R.exclude)});
-#endif
             // A non-finite ray (e.g. refract at the numerical edge of total reflection) is decided
             // by the reference loop in its own order; do that here and flag the ray as resolved
             // so the traversal kernel stays free of the fallback.
@@ -478,10 +482,7 @@ __device__ __forceinline__ uint32_t shade_store(const WfParams &P, uint32_t slot
                 if (COUNT) cn.prims += S.nprim;
                 resolved = 1u;
             }
-#ifndef CRT_WHATIF_NO_RAYW
             stnt(&P.ray_d[slot], float4{R.ray_d.x, R.ray_d.y, R.ray_d.z, bits_f(resolved)});
-#endif
-            stnt(&P.beta[slot], float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w});
             if (so.rad_dirty || (FINISH && !(R.flags & kWfHasRad))) {   // (k_wf_finish re-reads it every step: stored once)
                 stnt(&P.radiance[slot], float4{R.radiance.x, R.radiance.y, R.radiance.z, R.radiance.w});
                 R.flags |= kWfHasRad;
@@ -491,7 +492,8 @@ __device__ __forceinline__ uint32_t shade_store(const WfParams &P, uint32_t slot
             if (!FINISH) { const float4 x = ldnt(&P.sh_d[slot]); stnt(&P.sh_d[slot], float4{x.y, x.x, x.w, x.z}); }
 #endif
         }
-        stnt(&P.misc[slot], uint4{R.work, so.alive ? R.flags : 0u, f_bits(R.last_pdf), f_bits(R.etaScale)});
+        stnt(&P.beta[slot], so.alive ? float4{R.beta.x, R.beta.y, R.beta.z, R.beta.w} : float4{1.0f, 1.0f, 1.0f, 1.0f});
+        stnt(&P.misc[slot], so.alive ? uint4{R.work, R.flags, f_bits(R.last_pdf), f_bits(R.etaScale)} : uint4{0u, 0u, f_bits(1.0f), f_bits(1.0f)});
     }
     return resolved;
 }
@@ -822,11 +824,11 @@ __global__ __launch_bounds__(64) void k_wf_gen(const WfParams P, uint32_t it)
             const uint32_t lambda = (uint32_t)(301.0f * ul);                                  // :317-319
             const bool nan_ray = !finite3(eye) || !finite3(d);
             const uint32_t flags = kWfAlive | (lambda << kWfLambdaShift) | (sg << kWfBatchShift) | (nan_ray ? kWfNanRay : 0u);
-            stnt(&P.ray_o[slot], float4{eye.x, eye.y, eye.z, bits_f(0xFFFFFFFFu)});
+            // (ray_o = the eye, beta = 1, last_bounce_pdf = etaScale = 1 are in the slot already: k_wf_shade writes them into
+            // every dead slot with its coalesced streams)
             stnt(&P.ray_d[slot], float4{d.x, d.y, d.z, bits_f(0u)});
-            stnt(&P.beta[slot], float4{1.0f, 1.0f, 1.0f, 1.0f});
             stnt(&P.rng[slot], uint4{rng.x, rng.y, rng.z, rng.w});
-            stnt(&P.misc[slot], uint4{w0 + lane, flags, f_bits(1.0f), f_bits(1.0f)});   // work, flags, last_pdf, etaScale
+            stnt((uint2 *)&P.misc[slot], uint2{w0 + lane, flags});                   // work, flags
             // (a camera ray is finite unless the camera itself is not.  Such a ray is decided by the reference loop in its own
             // order like any other non-finite ray -- by the NEXT shade step (kWfNanRay): a call to that loop in this kernel would
             // cost it half its occupancy in registers, and the kernel sits between the shade and the traversal launch of its pipe)
@@ -1273,10 +1275,10 @@ __global__ __launch_bounds__(64, CRT_WF_MIN_WAVES) void k_wf_trace(const WfParam
 #define CRT_WF_PKFMA 0
 #endif
 #ifndef CRT_WF_LEAF2_AT
-#define CRT_WF_LEAF2_AT 32
+#define CRT_WF_LEAF2_AT 28
 #endif
 #ifndef CRT_WF_STALL_AT
-#define CRT_WF_STALL_AT 24
+#define CRT_WF_STALL_AT 16
 #endif
 constexpr int kStk2 = 16;
 #ifndef CRT_WF_RING
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
     __shared__ uint2 ring_l[kRing2];             //             (b_index, b_slot): the light's primitive for a shadow ray
     __shared__ unsigned long long cell[64];      // per lane: hit_key of its ray's best hit so far
     __shared__ uint32_t cslot[64];               // ... and that primitive's slot
-    __shared__ uint32_t tasks[64];               // owner lane | (primitive of its leaf) << 6
+    __shared__ uint2 tasks[64];                  // (primitive slot, owner lane): written by the owner, so a task lane's loads start after ONE DS read
     WfCtl *ctl = P.ctl;
     const uint4 *__restrict__ nodesq = P.sc.nodes4q;
     const f3 qscale = f3{P.sc.qscale[0], P.sc.qscale[1], P.sc.qscale[2]}, qbase = f3{P.sc.qbase[0], P.sc.qbase[1], P.sc.qbase[2]};
@@ -1487,19 +1489,30 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                 const uint32_t T = (uint32_t)(__popcll(c0 & mi) + 2 * __popcll(c1 & mi) + 4 * __popcll(c2 & mi) + 8 * __popcll(c3 & mi));
                 const uint32_t first = (~(uint32_t)lf) >> 3;
                 if (incl) {                                              // (the builders' leaves hold one to four primitives as a rule)
-                    tasks[pre] = lane;
-                    if (cnt > 1u) tasks[pre + 1u] = lane | (1u << 6);
-                    if (cnt > 2u) tasks[pre + 2u] = lane | (2u << 6);
-                    if (cnt > 3u) tasks[pre + 3u] = lane | (3u << 6);
-                    for (uint32_t i = 4; i < cnt; i++) tasks[pre + i] = lane | (i << 6);
+                    tasks[pre] = uint2{first, lane};
+                    if (cnt > 1u) tasks[pre + 1u] = uint2{first + 1u, lane};
+                    if (cnt > 2u) tasks[pre + 2u] = uint2{first + 2u, lane};
+                    if (cnt > 3u) tasks[pre + 3u] = uint2{first + 3u, lane};
+                    for (uint32_t i = 4; i < cnt; i++) tasks[pre + i] = uint2{first + i, lane};
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (COUNT) { d_leaf_it++; d_leaf_act += T; d_prim_it += 1u; }
                 // every lane shuffles (a bpermute reads active lanes only); lanes beyond T run on their own ray and do nothing
-                const uint32_t tk = lane < T ? tasks[lane] : lane;
-                const int owner = (int)(tk & 63u);
-                const uint32_t ps = (uint32_t)__shfl((int)first, owner, 64) + (tk >> 6);
+                const uint2 tk = lane < T ? tasks[lane] : uint2{0u, lane};
+                const int owner = (int)tk.y;
+                const uint32_t ps = tk.x;
+                // (the record loads go out first: the ray's values come over under their latency)
+                float4 A = float4{0, 0, 0, 0}, B = A, C = A, D = A;
+                if (lane < T) { A = prim[3 * (size_t)ps + 0]; B = prim[3 * (size_t)ps + 1]; C = prim[3 * (size_t)ps + 2]; D = primD[ps]; }
+                // the owners' next node meanwhile (it does not depend on the tests' outcome)
+                bool from_pend = false;
+                if (incl) {
+                    from_pend = pend != 0;
+                    if (from_pend) pend = 0;                             // the postponed leaf went first
+                    else if (sp > 0) { sp--; node = stack_pop2(stk, ovf, ovl, sp); }
+                    else node = kNoNode;
+                }
                 const f3 to = f3{__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64)};
                 const f3 td = f3{__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64)};
                 const uint32_t t_excl = (uint32_t)__shfl((int)excl, owner, 64);
@@ -1512,9 +1525,11 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                     uint32_t bi = low == 0xFFFFFFFFu ? kNoHit : 0xFFFFFFFEu - low;
                     const uint32_t bs0 = low == 0xFFFFFFFFu ? kNoHit : 0xFFFFFFFEu;     // "some hit" (no primitive has that slot)
                     uint32_t bs = bs0;
-                    const float4 A = prim[3 * (size_t)ps + 0], B = prim[3 * (size_t)ps + 1], C = prim[3 * (size_t)ps + 2];
+                    // (D, the patch record's fourth part, was fetched with the other three: 94 % of the rounds on S2 hold a wall patch
+                    // among their tasks, and fetched behind the category test it was a dependent round trip in every one of them)
                     if ((f_bits(A.w) & 3u) == 2u) tri_test(A, B, C, ps, to, td, t_excl, t_min, hit_pad, tm, bi, bs);
-                    else hit_test<false>(S, ps, to, td, t_excl, t_min, tm, bi, bs);
+                    else hit_test_rec<false>(A, B, C, D, hit_pad, ps, to, td, t_excl, t_min, tm, bi, bs);
+                    if (COUNT && __ballot((f_bits(A.w) & 3u) != 2u) != 0ull) d_scans += 64u;   // (probe: rounds that also run the patch / sphere test; read back / 64)
                     acc = bs != bs0;
                     if (acc) {
                         key = hit_key(tm, bi);
@@ -1533,9 +1548,6 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                     t_max = bits_f((uint32_t)(v >> 32));
                     b_index = low == 0xFFFFFFFFu ? kNoHit : 0xFFFFFFFEu - low;
                     b_slot = cslot[lane];
-                    if (pend != 0) pend = 0;                             // the postponed leaf went first
-                    else if (sp > 0) { sp--; node = stack_pop2(stk, ovf, ovl, sp); }
-                    else node = kNoNode;
                     bool done = false;
                     if (shadow && b_slot != b_slot_in) done = true;      // any-hit: something beats the light
                     else if (node == kNoNode && pend == 0) done = true;

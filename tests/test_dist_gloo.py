@@ -46,7 +46,15 @@ def _worker(rank, world, port, W, H, spp, out_dir, band=0):
     sc = orc.Scene.from_packed(ps)
     sf = StripFrame(W, H, world, rank, "cpu", band=band)
     if band:
-        rows = sf.rows[rank]
+        # this rank's rows from the C ABI's own definition of the partition (crt_layout_rows: what crt_comm_partition,
+        # crt_set_row_bands and the assembly kernel use; no GPU involved) -- must be the rows StripFrame gathers into
+        import ctypes as C
+        from computeraytracer_amd import _lib
+        n = C.c_uint32()
+        buf = np.zeros(H, np.uint32)
+        assert _lib.load().crt_layout_rows(H, band, world, rank, C.byref(n), buf.ctypes.data) == 0
+        rows = buf[: n.value].astype(np.int64)
+        assert np.array_equal(rows, np.asarray(sf.rows[rank]))
         acc = np.zeros((H, W, 4), np.float32)
         rgba = np.zeros((H, W, 4), np.uint8)
         for y in range(0, H, band):

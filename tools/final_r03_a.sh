@@ -11,12 +11,12 @@ step bench_mesh10k; timeout -k 10 200 python bench.py --scene mesh10k --spp 1 --
 step bench_4k;      timeout -k 10 300 python bench.py --width 3840 --height 2160 --spp 256 --steps 2 --warmup 1 --no-cpu-baseline > $o/bench_4k256.json 2> $o/bench_4k256.err
 step bench_soup;    timeout -k 10 400 python bench.py --scene soup --spp 16 --steps 4 --warmup 1 --no-cpu-baseline > $o/bench_soup10M.json 2> $o/bench_soup.err
 step bench_soup_lbvh; timeout -k 10 400 python bench.py --scene soup --spp 16 --steps 4 --warmup 1 --no-cpu-baseline --accel lbvh > $o/bench_soup10M_lbvh.json 2> $o/bench_soup_lbvh.err
-step bench_1pipe;   timeout -k 10 200 python bench.py --opt wf_pipes=1 --steps 4 --warmup 1 --no-cpu-baseline > $o/bench_single_pipe.json 2> $o/bench_single_pipe.err
+step bench_1pipe;   timeout -k 10 200 python bench.py --opt wf_pipes=1 --opt wf_waves_per_cu=20 --steps 4 --warmup 1 --no-cpu-baseline > $o/bench_single_pipe.json 2> $o/bench_single_pipe.err
 step bench_form1;   timeout -k 10 200 python bench.py --opt wf_trace_form=1 --steps 6 --warmup 2 --no-cpu-baseline > $o/bench_form1.json 2> $o/bench_form1.err
 step scene_ab;      bash tools/scene_ab.sh $o/scene_ab.txt > /dev/null 2>&1
 step kernel_stats;  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $o/prof -o p --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $o/prof_bench.json 2> $o/prof_bench.err
 python3 tools/timeline.py $o/prof/p_kernel_trace.csv > $o/timeline.txt 2>&1; cp $o/prof/p_kernel_stats.csv $o/kernel_stats.csv; rm -rf $o/prof
-step kernel_stats_1pipe; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $o/prof1 -o p --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --opt wf_pipes=1 > $o/prof_bench_1pipe.json 2> $o/prof_bench_1pipe.err
+step kernel_stats_1pipe; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $o/prof1 -o p --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --opt wf_pipes=1 --opt wf_waves_per_cu=20 > $o/prof_bench_1pipe.json 2> $o/prof_bench_1pipe.err
 cp $o/prof1/p_kernel_stats.csv $o/kernel_stats_single_pipe.csv; rm -rf $o/prof1
 step done_a
 ls $o

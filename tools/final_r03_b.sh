@@ -11,7 +11,8 @@ step traffic_s2;    timeout -k 10 600 python3 tools/traffic.py $o/traffic.json a
 step traffic_soup;  timeout -k 10 900 python3 tools/traffic.py $o/traffic.json soup 16 2 bvh2 > $o/traffic_soup.txt 2>&1
 step traffic_soup_lbvh; timeout -k 10 900 python3 tools/traffic.py $o/traffic.json soup 16 2 lbvh > $o/traffic_soup_lbvh.txt 2>&1
 step steady;        timeout -k 10 400 python tools/steady.py > $o/steady_state.log 2>&1
-step display;       python tools/dump_packed.py atrium250k 1920 1080 /tmp/s2 > /dev/null 2>&1 && timeout -k 10 200 node host/display_loop.js --packed /tmp/s2 --frames 640 --lag 32 --ring 64 > $o/display_loop_node.json 2> $o/display_loop_node.err
+step display;       python tools/dump_packed.py atrium250k 1920 1080 /tmp/s2 > /dev/null 2>&1 && timeout -k 10 200 node host/display_loop.js --packed /tmp/s2 --frames 2000 --lag 64 --ring 128 > $o/display_loop_node.json 2> $o/display_loop_node.err
+step display_py;    timeout -k 10 200 python tools/display_loop.py 2000 64 128 > $o/display_loop_py.txt 2>&1
 step latency;       timeout -k 10 200 python tools/latency.py > $o/latency_single_call.txt 2>&1
 step done
 ls $o
