@@ -24,6 +24,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints its version banner on STDOUT when a communicator is created; rank 0's stdout is ONE JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,10 +98,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+                t_ = torch.zeros(1, device=dev)
+                dist.all_reduce(t_)                      # (communicators are created at the first collective)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
 
     from computeraytracer_amd import Renderer, scenes_synth
     from computeraytracer_amd.distributed import StripFrame
@@ -119,10 +140,11 @@ def main():
     native = args.gather == "native"
     if native:
         # the communicator of the C ABI: rank 0 makes the RCCL id (ncclGetUniqueId inside libcrt), the others get it
-        ids = [Renderer.comm_unique_id(local=False) if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        r.comm_init(ids[0], rank, world)
+        with stdout_to_stderr():
+            ids = [Renderer.comm_unique_id(local=False) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            r.comm_init(ids[0], rank, world)
     r.upload(ps)
     for o in args.opt:
         k, v = o.split("=")
@@ -364,7 +386,7 @@ def kernel_sources_sha256():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "computeraytracer_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):     # (crt_api.cpp: the pool size there sets the launch size)
+        if name.endswith((".hip", ".h")) or name in ("crt_api.cpp", "crt_bvh.cpp"):     # (crt_api.cpp: the pool size sets the launch size; crt_bvh.cpp: the tree)
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()

@@ -94,6 +94,8 @@ struct Comm {
     uint64_t n_rgba = 0, n_accum = 0;                        // gathers posted by this rank
     uint64_t asm_rgba = 0, asm_accum = 0;                    // ... and assembled
     hipEvent_t ev_rgba = nullptr, ev_accum = nullptr;        // local transport: after this rank's copies of its latest gather
+    hipEvent_t ev_asm_rgba = nullptr, ev_asm_accum = nullptr;  // ... and after this rank's latest assembly (it reads `full`: a peer's next copy waits for it)
+    bool asm_rgba_recorded = false, asm_accum_recorded = false;
 };
 std::map<crt_ctx *, std::unique_ptr<Comm>> g_comms;
 std::map<std::string, std::weak_ptr<LocalGroup>> g_groups;
@@ -204,7 +206,8 @@ int crt_comm_init(crt_ctx *c, const void *id, int rank, int world)
         const ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, uid, rank);   // (collective: every rank of the id calls it)
         if (r != ncclSuccess) return fail(c, CRT_EDEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
     }
-    if (hipEventCreateWithFlags(&m->ev_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_accum, hipEventDisableTiming) != hipSuccess)
+    if (hipEventCreateWithFlags(&m->ev_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_accum, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_asm_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_asm_accum, hipEventDisableTiming) != hipSuccess)
         return fail(c, CRT_EDEVICE, "crt_comm_init: hipEventCreate failed");
     std::lock_guard<std::mutex> lk(g_mu);
     g_comms[c] = std::move(m);
@@ -230,6 +233,8 @@ int crt_comm_destroy(crt_ctx *c)
     if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);
     if (m->ev_rgba) (void)hipEventDestroy(m->ev_rgba);
     if (m->ev_accum) (void)hipEventDestroy(m->ev_accum);
+    if (m->ev_asm_rgba) (void)hipEventDestroy(m->ev_asm_rgba);
+    if (m->ev_asm_accum) (void)hipEventDestroy(m->ev_asm_accum);
     return CRT_OK;
 }
 
@@ -300,6 +305,8 @@ static int gather_one(crt_ctx *c, Comm *m, bool accum)
         if (p->rows_max != m->rows_max || p->W != m->W || p->H != m->H || p->band != m->band)
             return fail(c, CRT_EINVAL, "crt_gather: the ranks of the communicator disagree about the partition");
         char *pd = (char *)(accum ? p->full_accum : p->full_rgba) + (size_t)m->rank * strip_bytes;
+        // (the peer's assembly of the PREVIOUS gather reads the buffer this copy writes: behind it, whatever the streams)
+        if (p != m && (accum ? p->asm_accum_recorded : p->asm_rgba_recorded)) CHIP(c, hipStreamWaitEvent(s, accum ? p->ev_asm_accum : p->ev_asm_rgba, 0));
         CHIP(c, hipMemcpyPeerAsync(pd, p->device, src, m->device, strip_bytes, s));
     }
     CHIP(c, hipEventRecord(accum ? m->ev_accum : m->ev_rgba, s));
@@ -343,6 +350,10 @@ static int assemble(crt_ctx *c, Comm *m, bool accum, hipStream_t s)
                                                   m->W, m->H, (uint32_t)m->world, std::max(m->rows_max, 1u), m->band, s);
         if (e != hipSuccess) return fail(c, CRT_EDEVICE, std::string("frame assembly: ") + hipGetErrorString(e));
         done = posted;
+        if (m->local) {
+            CHIP(c, hipEventRecord(accum ? m->ev_asm_accum : m->ev_asm_rgba, s));
+            (accum ? m->asm_accum_recorded : m->asm_rgba_recorded) = true;
+        }
     }
     return CRT_OK;
 }

@@ -130,7 +130,10 @@ def test_atrium250k_1080p_crops_vs_oracle(renderer, orc):
     from computeraytracer_amd.scenes_synth import atrium250k
     ps = atrium250k(1920, 1080)
     assert len(ps.primitives) == 6 + 253952
-    _crops_vs_oracle(renderer, orc, ps, 1, [(940, 600, 972, 616), (700, 400, 732, 416), (1100, 820, 1132, 836)])
+    # (four fused samples: the pool then holds paths of several samples and bounces at once; crops on the floor, the columns,
+    # the ceiling light, a wall and a frame corner)
+    _crops_vs_oracle(renderer, orc, ps, 4, [(940, 600, 988, 624), (700, 400, 748, 424), (1100, 820, 1148, 844), (930, 20, 978, 44),
+                                            (0, 500, 32, 524), (1888, 1056, 1920, 1080)])
 
 
 def test_soup_vs_oracle(renderer, orc):
