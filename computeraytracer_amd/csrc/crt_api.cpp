@@ -132,6 +132,7 @@ struct crt_ctx {
     uint32_t frame_ring = 0;
     std::vector<uint8_t> frame_batch;   // per ring slot: the batch id whose resolve pass wrote that frame (its ev_resolved orders a read)
     hipStream_t read_stream = nullptr;  // readbacks from the ring: they wait for the frame's own resolve pass, not for the retirement work queued behind it
+    uint32_t ring_from = 1;         // the ring holds frames of samples >= this (a restored accumulator brings no frames with it)
     uint32_t resolved_upto = 0;     // samples whose resolve pass has been enqueued on the context's stream (frames <= this are in the ring / the framebuffer in stream order)
     float4 *accum_bound = nullptr;
     uchar4 *rgba_bound = nullptr;
@@ -254,7 +255,7 @@ int zero_state(crt_ctx *c)
         HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, n * sizeof(float4), c->stream));
         HIPCHK(c, hipMemsetAsync(rgba_ptr(c), 0, n * sizeof(uchar4), c->stream));
     }
-    c->sample = 0; c->published = 0; c->pending = 0; c->resolved_upto = 0;
+    c->sample = 0; c->published = 0; c->pending = 0; c->resolved_upto = 0; c->ring_from = 1;
     return CRT_OK;
 }
 
@@ -1921,6 +1922,7 @@ int crt_read_sample_rgba8(crt_ctx *c, uint32_t sample, uint8_t *out)
     if (!c->have_scene) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: no scene");
     if (!c->frame_ring || !c->d_frames.p) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: set option frame_ring first (frames kept per sample)");
     if (sample == 0 || sample > c->sample) return fail(c, CRT_EINVAL, "crt_read_sample_rgba8: sample %u has not been requested (1..%u)", sample, c->sample);
+    if (sample < c->ring_from) return fail(c, CRT_EINVAL, "crt_read_sample_rgba8: sample %u was not traced by this context since its last reset / crt_write_accum (frames from %u on)", sample, c->ring_from);
     if (c->sample - sample >= c->frame_ring) return fail(c, CRT_EINVAL, "crt_read_sample_rgba8: sample %u has left the ring of %u frames (%u requested)", sample, c->frame_ring, c->sample);
     if (c->pipeline != 1 || c->accel_mode != CRT_ACCEL_BVH2) return fail(c, CRT_ESTATE, "crt_read_sample_rgba8: frames are kept by the wavefront pipeline only");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1945,7 +1947,7 @@ int crt_write_accum(crt_ctx *c, const float *in, uint32_t sample)
     size_t n = (size_t)c->tw * c->th;
     if (n) HIPCHK(c, hipMemcpyAsync(accum_ptr(c), in, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->sample = sample; c->published = sample; c->pending = 0; c->resolved_upto = sample;
+    c->sample = sample; c->published = sample; c->pending = 0; c->resolved_upto = sample; c->ring_from = sample + 1u;
     return CRT_OK;
 }
 
@@ -2095,6 +2097,7 @@ int crt_set_option(crt_ctx *c, const char *name, int64_t value)
     if (!std::strcmp(name, "wf_tail_walk")) { c->wf_tail_walk = value != 0; return CRT_OK; }
     if (!std::strcmp(name, "frame_ring")) {
         c->frame_ring = (uint32_t)std::min<int64_t>(256, std::max<int64_t>(0, value));
+        c->ring_from = c->sample + 1u;                          // (a new ring starts empty)
         if (c->have_scene) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return alloc_frames(c); }
         return CRT_OK;
     }
