@@ -41,7 +41,11 @@ CRT_HD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 CRT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 CRT_HD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 CRT_HD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+#ifdef CRT_PROBE_RCP   /* probe build (wrong image): what the vector / scalar divisions cost */
+CRT_HD f3 operator/(f3 a, float s) { const float r = 1.0f / s; return f3{a.x * r, a.y * r, a.z * r}; }
+#else
 CRT_HD f3 operator/(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
+#endif
 CRT_HD float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 CRT_HD f3 cross(f3 a, f3 b) {
     return f3{fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};
@@ -54,7 +58,11 @@ CRT_HD f4 F4(float x, float y, float z, float w) { return f4{x, y, z, w}; }
 CRT_HD f4 operator+(f4 a, f4 b) { return f4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 CRT_HD f4 operator*(f4 a, f4 b) { return f4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
 CRT_HD f4 operator*(f4 a, float s) { return f4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+#ifdef CRT_PROBE_RCP
+CRT_HD f4 operator/(f4 a, float s) { const float r = 1.0f / s; return f4{a.x * r, a.y * r, a.z * r, a.w * r}; }
+#else
 CRT_HD f4 operator/(f4 a, float s) { return f4{a.x / s, a.y / s, a.z / s, a.w / s}; }
+#endif
 CRT_HD float dot(f4 a, f4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
 
 CRT_HD float pow2i(int n) { return bits_f((uint32_t)(n + 127) << 23); }  // n in [-126,127]
