@@ -95,6 +95,7 @@ static int get_bytes(napi_env env, napi_value v, void **data, size_t *len)
         napi_typedarray_type t; size_t n, off; napi_value ab;
         if (napi_get_typedarray_info(env, v, &t, &n, data, &ab, &off) != napi_ok) return 0;
         static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        if ((size_t)t >= sizeof esz / sizeof esz[0]) return 0;      /* (an element type this table does not know) */
         *len = n * esz[t];
         return 1;
     }

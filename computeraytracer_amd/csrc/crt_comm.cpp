@@ -182,6 +182,16 @@ int crt_comm_init(crt_ctx *c, const void *id, int rank, int world)
     m->ctx = c; m->rank = rank; m->world = world; m->device = device;
     std::memcpy(m->id, id, CRT_COMM_ID_BYTES);
     m->local = is_local_id(id);
+    // (the events first: nothing below may fail once the rank has joined its group or its RCCL communicator exists)
+    auto drop_events = [&]() {
+        for (hipEvent_t *e : {&m->ev_rgba, &m->ev_accum, &m->ev_asm_rgba, &m->ev_asm_accum}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    };
+    if (hipEventCreateWithFlags(&m->ev_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_accum, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_asm_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_asm_accum, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        drop_events();
+        return fail(c, CRT_EDEVICE, "crt_comm_init: hipEventCreate failed");
+    }
     if (m->local) {
         std::lock_guard<std::mutex> lk(g_mu);
         const std::string key((const char *)id, CRT_COMM_ID_BYTES);
@@ -192,23 +202,20 @@ int crt_comm_init(crt_ctx *c, const void *id, int rank, int world)
             g->posted_rgba.assign((size_t)world, 0); g->posted_accum.assign((size_t)world, 0);
             g_groups[key] = g;
         }
-        if (g->world != world) return fail(c, CRT_EINVAL, "crt_comm_init: the ranks of one id disagree about the world size");
-        if (g->member[(size_t)rank]) return fail(c, CRT_EINVAL, "crt_comm_init: that rank of the id is taken");
+        if (g->world != world) { drop_events(); return fail(c, CRT_EINVAL, "crt_comm_init: the ranks of one id disagree about the world size"); }
+        if (g->member[(size_t)rank]) { drop_events(); return fail(c, CRT_EINVAL, "crt_comm_init: that rank of the id is taken"); }
         g->member[(size_t)rank] = m.get();
         m->group = g;
     } else {
         {
             std::lock_guard<std::mutex> lk(g_mu);
-            if (!g_rccl.load()) return fail(c, CRT_EDEVICE, "crt_comm_init: " + g_rccl.err);
+            if (!g_rccl.load()) { drop_events(); return fail(c, CRT_EDEVICE, "crt_comm_init: " + g_rccl.err); }
         }
         ncclUniqueId uid;
         std::memcpy(&uid, id, sizeof uid);
         const ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, uid, rank);   // (collective: every rank of the id calls it)
-        if (r != ncclSuccess) return fail(c, CRT_EDEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+        if (r != ncclSuccess) { drop_events(); return fail(c, CRT_EDEVICE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
     }
-    if (hipEventCreateWithFlags(&m->ev_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_accum, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_asm_rgba, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_asm_accum, hipEventDisableTiming) != hipSuccess)
-        return fail(c, CRT_EDEVICE, "crt_comm_init: hipEventCreate failed");
     std::lock_guard<std::mutex> lk(g_mu);
     g_comms[c] = std::move(m);
     return CRT_OK;
