@@ -44,8 +44,8 @@ def stdout_to_stderr():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)            # (1.7 s of timed GPU work at 64 spp per step: long enough for an outside busy-sampler to see it)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="atrium250k", choices=["cornell", "mesh10k", "atrium250k", "soup"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
