@@ -1044,6 +1044,12 @@ bool wf_has_room(crt_ctx *c)
 //  I8  Every loop below makes progress or blocks on something the device will complete: a launch is always enqueued
 //      behind the status being waited for (the record is written by the NEXT launch), back-pressure waits are on events
 //      recorded behind enqueued work, and a wall-clock watchdog turns a violated assumption into CRT_EDEVICE + state dump.
+//  I9  A flush returns with its finish / resolve passes still QUEUED on the context's stream (only crt_sync and the reads
+//      wait for them).  Everything a new run starts is therefore ordered behind that stream: the pool's set-up runs on it,
+//      the pipes AND the publishing stream wait for its fork event.  (I6's device-side waits are per run -- resolved_recorded
+//      starts afresh -- so without the fork wait the reset of the new run's second batch could zero the side counters
+//      under the previous run's k_wf_finish: round 3's lost-paths defect, test_flush_without_host_sync_then_quick_batches.)
+//      WfCtl::dropped is never reset by a set-up, only once the host has reported it.
 //
 // Feed the pool: enqueue the iterations the published work needs (see the head of this section).  for_room = false:
 // return once they are enqueued (the call does not wait for its work); for_room = true: keep feeding and reading
@@ -1276,6 +1282,9 @@ int wf_check_dropped(crt_ctx *c)
         if (c->h_dropped[p]) {
             const uint32_t n = c->h_dropped[p];
             c->h_dropped[p] = 0;
+            // (the device counter is not reset by the pool's set-up -- a flush in the middle of a run must not lose what an
+            // earlier one counted -- but here, once reported)
+            if (c->w_ctl[p].p) (void)hipMemsetAsync(&c->w_ctl[p].p->dropped, 0, sizeof(uint32_t), c->stream);
             return fail(c, CRT_EDEVICE, "wavefront pipeline: a capacity guard dropped %u paths (pipe %d); the frame is incomplete", n, p);
         }
     return CRT_OK;
@@ -1460,6 +1469,11 @@ int wf_trace_batch(crt_ctx *c, uint32_t n)
             HIPCHK(c, hipStreamWaitEvent(r.pipes[p].stream, c->ev_fork, 0));
             if (p > 0) HIPCHK(c, wf_launch_init(r.pipes[p].W, r.pipes[p].stream));
         }
+        // The publishing stream too: the finish / resolve passes of the PREVIOUS run may still be queued on the context's
+        // stream (a flush returns without waiting for them), and the queue / side-counter reset of this run's second batch
+        // must not overtake them -- resolved_recorded, which orders that reset within a run, starts afresh here.  (A reset
+        // that did: k_wf_finish found side_count 0 and the batch lost its last paths -- tests: display state machine walk.)
+        HIPCHK(c, hipStreamWaitEvent(c->pub_stream, c->ev_fork, 0));
         r.live = true;
     } else {
         // room in the ring first (back-pressure: the oldest batch has to retire; the pool is fed meanwhile)

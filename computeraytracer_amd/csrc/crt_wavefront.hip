@@ -1770,7 +1770,7 @@ __global__ void k_wf_init(const WfParams P)
                 c->shard[r][i].cur = 0; c->shard[r][i].n_dead = 0;
                 for (uint32_t b = 0; b < kWfRing; b++) c->shard[r][i].alive[b] = 0;
             }
-        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else { for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; c->dropped = 0; } }
+        if (i == 0) { if (P.keep_pool) c->side_count[P.batch_id] = 0; else for (uint32_t b = 0; b < kWfRing; b++) c->side_count[b] = 0; }   // (dropped: kept until the host has reported it)
         if (P.reset_wq) {
             P.wq[P.batch_id].work[i].cur = 0;
             if (i == 0) {

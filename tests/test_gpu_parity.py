@@ -865,6 +865,111 @@ def test_every_frame_of_a_pipelined_run_can_be_shown_once(renderer, orc):
         renderer.set_option("frame_ring", 0).set_option("wf_cohort", 16)
 
 
+def test_display_state_machine_random_walk(renderer, orc):
+    """Seeded random sequences of small crt_trace calls with the non-flushing reads in between -- crt_read_sample_rgba8 of a
+    random frame still in the ring, crt_read_latest_rgba8, crt_latest_sample -- over random driver settings (pipes, batch
+    ring, cohort, frame ring, chunk size, eviction thresholds): every frame handed out is the oracle's frame of that sample
+    index, bit for bit, the indices crt_latest_sample reports never go back, and the run ends on the oracle's frame."""
+    from computeraytracer_amd import cornell
+    W = H = 96
+    ps = cornell(W, H)
+    sc = orc.Scene.from_packed(ps)
+    frames = {}
+
+    def want(k):
+        if k not in frames:
+            frames[k] = sc.render(k)[1]
+        return frames[k]
+
+    rng = np.random.default_rng(20261005)
+    renderer.upload(ps).build_accel("bvh2")
+    try:
+        for epoch in range(int(os.environ.get("CRT_TEST_EPOCHS", "8"))):
+            opts = {"wf_pipes": int(rng.choice([1, 2, 2, 4])), "wf_ring": int(rng.choice([2, 3, 32])), "wf_cohort": int(rng.choice([1, 4, 8, 16])),
+                    "frame_ring": int(rng.choice([8, 17, 64])), "wf_chunk": int(rng.choice([1, 2, 4])), "wf_pool": int(rng.choice([0, 1 << 14, 1 << 16])),
+                    "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096]))}
+            for k, v in opts.items():
+                renderer.set_option(k, v)
+            renderer.reset()
+            total, latest_seen, log = 0, 0, []
+            for _ in range(int(rng.integers(6, 40))):
+                n = int(rng.choice([1, 1, 1, 2, 3]))
+                if total + n > 60:
+                    break
+                renderer.frame(n)
+                total += n
+                what = rng.random()
+                if what < 0.35:
+                    lo = max(1, total - opts["frame_ring"] + 1)
+                    k = int(rng.integers(lo, total + 1))
+                    log.append(("sample", k))
+                    assert np.array_equal(renderer.read_sample_rgba8(k), want(k)), (epoch, opts, log)
+                elif what < 0.5:
+                    img, s = renderer.read_latest_rgba8()
+                    log.append(("latest", s))
+                    assert latest_seen <= s <= total, (epoch, opts, log)
+                    latest_seen = s
+                    if s:
+                        assert np.array_equal(img, want(s)), (epoch, opts, log)
+                elif what < 0.6:
+                    s = renderer.latest_sample
+                    log.append(("query", s))
+                    assert latest_seen <= s <= total, (epoch, opts, log)
+                    latest_seen = s
+                elif what < 0.65:
+                    renderer.sync()
+                    log.append(("sync", total))
+                    assert renderer.latest_sample == total
+                    latest_seen = total
+            renderer.sync()
+            print(epoch, opts, total, log)               # (shown by pytest if a comparison fails)
+            assert renderer.sample == total and renderer.latest_sample == total
+            if total:
+                assert np.array_equal(renderer.read_rgba8(), want(total))
+                lo = max(1, total - opts["frame_ring"] + 1)
+                assert np.array_equal(renderer.read_sample_rgba8(lo), want(lo))
+    finally:
+        for k, v in {"wf_pipes": 2, "wf_ring": 32, "wf_cohort": 16, "frame_ring": 0, "wf_chunk": 1, "wf_pool": 0, "wf_finish_at": 32768,
+                     "wf_flush_at": 4096}.items():
+            renderer.set_option(k, v)
+
+
+def test_flush_without_host_sync_then_quick_batches(renderer, orc):
+    """Regression (found by the walk above): a flush that the driver makes on its own (here: a one-sample batch after
+    three-sample ones wants a pool less than half the size) returns with the last batches' finish / resolve passes still
+    queued on the context's stream; the queue / side-counter reset of the NEW run's second batch, on the publishing stream,
+    overtook them, k_wf_finish found side_count 0 and the paths evicted at the flush were lost (two to fifty pixels short of
+    a sample, two runs in three).  The exact sequence, six times: every frame is the oracle's."""
+    from computeraytracer_amd import cornell
+    W = H = 96
+    ps = cornell(W, H)
+    sc = orc.Scene.from_packed(ps)
+    want = {k: sc.render(k)[1] for k in (1, 3, 17, 24)}
+    acc24 = sc.render(24)[0]
+    renderer.upload(ps).build_accel("bvh2")
+    opts = {"wf_pipes": 2, "wf_ring": 3, "wf_cohort": 1, "frame_ring": 17, "wf_chunk": 4, "wf_finish_at": 0, "wf_flush_at": 256}
+    try:
+        for k, v in opts.items():
+            renderer.set_option(k, v)
+        for rep in range(6):
+            renderer.reset()
+            renderer.frame(2).frame(1).frame(1).frame(1).sync()
+            renderer.frame(3)
+            renderer.frame(1).frame(1).frame(1).sync()                        # 11
+            renderer.frame(3)
+            assert np.array_equal(renderer.read_sample_rgba8(3), want[3])     # (a read that does not flush: the host falls behind)
+            renderer.frame(3)
+            assert np.array_equal(renderer.read_sample_rgba8(1), want[1])
+            renderer.frame(1).frame(1).frame(1)                               # 18 (the pool shrinks: flush), 19, 20
+            assert np.array_equal(renderer.read_sample_rgba8(17), want[17]), rep
+            renderer.frame(2).frame(2).sync()
+            assert renderer.sample == 24
+            assert_same_image(renderer.read_accum(), renderer.read_rgba8(), acc24, want[24])
+    finally:
+        for k, v in {"wf_pipes": 2, "wf_ring": 32, "wf_cohort": 16, "frame_ring": 0, "wf_chunk": 1, "wf_finish_at": 32768, "wf_flush_at": 4096}.items():
+            renderer.set_option(k, v)
+
+
 # ------------------------------------------------------------------ multi-GPU through the C ABI
 @pytest.mark.parametrize("world,band", [(2, 8), (3, 0), (4, 5)])
 def test_native_gather_assembles_the_single_gpu_frame(orc, world, band):
