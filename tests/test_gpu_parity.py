@@ -5,6 +5,7 @@ benchmark sizes (tile-partition invariance, fused-vs-incremental samples,
 BVH == the reference's own loop)."""
 import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -460,7 +461,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096])),
                     "wf_tail_walk": int(rng.choice([0, 1])), "wf_defer": int(rng.choice([1, 1, 1, 0])),
                     "wf_ring": int(rng.choice([2, 3, 4, 32])), "wf_pool_spp": int(rng.choice([1, 2, 4])), "wf_ahead": int(rng.choice([2, 3, 6])),
-                    "wf_cohort": int(rng.choice([1, 1, 4, 16]))}
+                    "wf_cohort": int(rng.choice([1, 1, 4, 16])), "wf_trace_form": int(rng.choice([1, 2, 2])),
+                    "wf_gen_blocks": int(rng.choice([1, 16, 128])), "wf_waves_per_cu": int(rng.choice([0, 2, 13]))}
             for k, v in opts.items():
                 renderer.set_option(k, v)
             rect = None
@@ -480,6 +482,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
                     renderer.sync()
                 elif what < 0.3:
                     renderer.read_rgba8()
+                elif what < 0.5:
+                    time.sleep(float(rng.random()) * 0.003)     # (the host falls behind the device, or the other way round)
             renderer.sync()
             if total not in full:
                 full[total] = sc.render(total)[:2]
@@ -488,7 +492,8 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
             assert renderer.sample == total
     finally:
         for k, v in {"wf_pool": 0, "wf_pipes": 2, "wf_chunk": 1, "wf_feed_pct": 100, "wf_finish_at": 32768, "wf_ahead": 3,
-                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 8, "wf_cohort": 16}.items():
+                     "wf_flush_at": 4096, "wf_tail_walk": 1, "wf_defer": 1, "wf_ring": 32, "wf_pool_spp": 8, "wf_cohort": 16,
+                     "wf_trace_form": 2, "wf_gen_blocks": 128, "wf_waves_per_cu": 0}.items():
             renderer.set_option(k, v)
 
 
@@ -921,6 +926,8 @@ def test_display_state_machine_random_walk(renderer, orc):
                     log.append(("sync", total))
                     assert renderer.latest_sample == total
                     latest_seen = total
+                elif what < 0.8:
+                    time.sleep(float(rng.random()) * 0.003)
             renderer.sync()
             print(epoch, opts, total, log)               # (shown by pytest if a comparison fails)
             assert renderer.sample == total and renderer.latest_sample == total
@@ -999,6 +1006,69 @@ def test_native_gather_assembles_the_single_gpu_frame(orc, world, band):
     finally:
         for r in rs:
             r.close()
+
+
+def test_native_gather_random_walk_shows_only_complete_frames(orc):
+    """The gather path under a display loop's pacing: seeded random sequences in which the ranks (contexts on device 0,
+    in-process transport) trace at different paces, gather in the middle of the run in random rank order, and a random
+    rank reads the assembled frame.  What crt_trace promises for bound outputs must hold row by row: each rank's rows
+    of an assembled frame are the oracle's frame after SOME number of samples that rank had been asked for by then --
+    complete, never a half-resolved one, and never older than the rank's previous gather showed; after a sync of every
+    rank the frame is the oracle's at the full count."""
+    from computeraytracer_amd import Renderer, cornell
+    from computeraytracer_amd.partition import strip_rows, band_rows
+    W, H, K = 64, 50, 20
+    ps = cornell(W, H)
+    sc = orc.Scene.from_packed(ps)
+    frames = {0: np.zeros((H, W, 4), np.uint8)}
+    for k in range(1, K + 1):
+        frames[k] = sc.render(k)[1]
+    rng = np.random.default_rng(20261006)
+    for epoch in range(int(os.environ.get("CRT_TEST_EPOCHS", "8")) // 2):
+        world, band = int(rng.choice([2, 3])), int(rng.choice([0, 4, 8]))
+        cid = Renderer.comm_unique_id(local=True)
+        rs = [Renderer(0) for _ in range(world)]
+        try:
+            for k, r in enumerate(rs):
+                r.comm_init(cid, k, world).upload(ps).comm_partition(band).build_accel("bvh2")
+                r.set_option("wf_cohort", int(rng.choice([1, 2, 16]))).set_option("wf_pool", int(rng.choice([0, 1 << 14])))
+            rows = [np.arange(*strip_rows(H, world, k)) if band == 0 else band_rows(H, world, k, band) for k in range(world)]
+            asked, shown = [0] * world, [0] * world
+            for _ in range(int(rng.integers(4, 14))):
+                for k in rng.permutation(world):
+                    n = int(rng.choice([0, 1, 1, 2, 3]))
+                    if asked[k] + n <= K and n:
+                        rs[k].frame(n)
+                        asked[k] += n
+                    if rng.random() < 0.3:
+                        time.sleep(float(rng.random()) * 0.002)
+                if rng.random() < 0.2:
+                    for r in rs:
+                        r.sync()
+                for k in rng.permutation(world):
+                    rs[k].gather(rgba8=True)
+                img = rs[int(rng.integers(0, world))].read_frame_rgba8()
+                for k in range(world):
+                    if len(rows[k]) == 0:
+                        continue
+                    match = [j for j in range(shown[k], asked[k] + 1) if np.array_equal(img[rows[k]], frames[j][rows[k]])]
+                    assert match, (epoch, world, band, k, shown, asked)
+                    shown[k] = match[0]
+            for r in rs:
+                r.sync()
+            for k in rng.permutation(world):
+                rs[k].gather(rgba8=True, accum=True)
+            total = asked[0]
+            if all(a == total for a in asked) and total:
+                assert_same_image(rs[0].read_frame_accum(), rs[0].read_frame_rgba8(), *sc.render(total)[:2])
+            else:
+                img = rs[-1].read_frame_rgba8()
+                for k in range(world):
+                    if len(rows[k]):
+                        assert np.array_equal(img[rows[k]], frames[asked[k]][rows[k]]), (epoch, k, asked)
+        finally:
+            for r in rs:
+                r.close()
 
 
 def test_native_gather_over_rccl_single_rank():
