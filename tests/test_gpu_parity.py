@@ -876,7 +876,7 @@ def test_display_state_machine_random_walk(renderer, orc):
     ring, cohort, frame ring, chunk size, eviction thresholds): every frame handed out is the oracle's frame of that sample
     index, bit for bit, the indices crt_latest_sample reports never go back, and the run ends on the oracle's frame."""
     from computeraytracer_amd import cornell
-    W = H = 96
+    W = H = 160                                     # (large enough for two and four pipes when the ring allows: 25 600 x 31 work items)
     ps = cornell(W, H)
     sc = orc.Scene.from_packed(ps)
     frames = {}
@@ -891,7 +891,7 @@ def test_display_state_machine_random_walk(renderer, orc):
     try:
         for epoch in range(int(os.environ.get("CRT_TEST_EPOCHS", "8"))):
             opts = {"wf_pipes": int(rng.choice([1, 2, 2, 4])), "wf_ring": int(rng.choice([2, 3, 32])), "wf_cohort": int(rng.choice([1, 4, 8, 16])),
-                    "frame_ring": int(rng.choice([8, 17, 64])), "wf_chunk": int(rng.choice([1, 2, 4])), "wf_pool": int(rng.choice([0, 1 << 14, 1 << 16])),
+                    "frame_ring": int(rng.choice([8, 17, 64])), "wf_chunk": int(rng.choice([1, 2, 4])), "wf_pool": int(rng.choice([0, 1 << 16, 1 << 19, 1 << 20])),
                     "wf_finish_at": int(rng.choice([0, 512, 32768])), "wf_flush_at": int(rng.choice([0, 64, 4096]))}
             for k, v in opts.items():
                 renderer.set_option(k, v)
@@ -899,7 +899,7 @@ def test_display_state_machine_random_walk(renderer, orc):
             total, latest_seen, log = 0, 0, []
             for _ in range(int(rng.integers(6, 40))):
                 n = int(rng.choice([1, 1, 1, 2, 3]))
-                if total + n > 60:
+                if total + n > 40:
                     break
                 renderer.frame(n)
                 total += n
