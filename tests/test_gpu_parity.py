@@ -484,6 +484,9 @@ def test_pipeline_state_machine_random_walk(renderer, orc):
                     renderer.read_rgba8()
                 elif what < 0.5:
                     time.sleep(float(rng.random()) * 0.003)     # (the host falls behind the device, or the other way round)
+                elif what < 0.6:
+                    # an option changed in the middle of the run: a flush WITHOUT a host synchronisation, then a new pool
+                    renderer.set_option("wf_chunk", int(rng.choice([1, 2, 4]))).set_option("wf_ahead", int(rng.choice([2, 3, 6])))
             renderer.sync()
             if total not in full:
                 full[total] = sc.render(total)[:2]
@@ -928,6 +931,9 @@ def test_display_state_machine_random_walk(renderer, orc):
                     latest_seen = total
                 elif what < 0.8:
                     time.sleep(float(rng.random()) * 0.003)
+                elif what < 0.85:
+                    renderer.set_option("wf_chunk", int(rng.choice([1, 2, 4])))     # (a flush without a host synchronisation, then a new pool)
+                    log.append(("option", total))
             renderer.sync()
             print(epoch, opts, total, log)               # (shown by pytest if a comparison fails)
             assert renderer.sample == total and renderer.latest_sample == total
