@@ -338,6 +338,8 @@ int build_accel_on_device(crt_ctx *c, bool *done)
     c->sc.nodes4q = c->d_nodes4q.p;
     c->sc.nodes8q = nullptr; c->sc.root8 = -1;
     c->sc.nprim = n;
+    c->sc.npatch = 0;
+    for (const HostPrim &hp_ : c->prims) c->sc.npatch += hp_.category == 0u ? 1u : 0u;
     c->accel_mode = CRT_ACCEL_BVH2;
     *done = true;
     return CRT_OK;
@@ -490,6 +492,8 @@ int upload_geometry(crt_ctx *c, int mode)
     c->sc.nodes = c->d_nodes.p;
     c->sc.root = c->bvh.root;
     c->sc.nprim = n;
+    c->sc.npatch = 0;
+    for (const HostPrim &hp_ : c->prims) c->sc.npatch += hp_.category == 0u ? 1u : 0u;
     c->accel_mode = mode;
     return CRT_OK;
 }

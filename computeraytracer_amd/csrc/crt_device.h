@@ -39,6 +39,7 @@ struct DevScene {
     const float *cie;
     const float4 *lights;
     uint32_t nprim;
+    uint32_t npatch;       // planar patches (category 0) in the scene: with none, nobody needs primD
     int32_t root;
     int32_t root4;
     int32_t root8;

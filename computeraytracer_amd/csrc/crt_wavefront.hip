@@ -50,6 +50,9 @@ namespace crt {
 #ifndef CRT_WF_SPEC
 #define CRT_WF_SPEC 1
 #endif
+#ifndef CRT_WF_PATCH_RECOMPUTE
+#define CRT_WF_PATCH_RECOMPUTE 0xFFFFFFFFu      /* k_wf_trace2 recomputes a patch's fourth record part in scenes with at most this many patches: always */
+#endif
 #ifndef CRT_WF_SHADE_BLOCK
 #define CRT_WF_SHADE_BLOCK 64
 #endif
@@ -299,7 +302,7 @@ __device__ __forceinline__ ShadeOut shade_body(const WfParams &P, uint32_t slot,
     const uint32_t h_slot = f_bits(h.y);
     const bool has_hit = alive && !nan_ray && !(R.flags & kWfDying) && h_slot != kNoHit;
     float4 hA = float4{0, 0, 0, 0}, hB = hA, hC = hA, hD = hA;
-    if (has_hit) { hA = S.prim[3 * (size_t)h_slot + 0]; hB = S.prim[3 * (size_t)h_slot + 1]; hC = S.prim[3 * (size_t)h_slot + 2]; hD = S.primD[h_slot]; }
+    if (has_hit) { hA = S.prim[3 * (size_t)h_slot + 0]; hB = S.prim[3 * (size_t)h_slot + 1]; hC = S.prim[3 * (size_t)h_slot + 2]; if (S.npatch) hD = S.primD[h_slot]; }
     CRT_PROBE(tp, 2)
 
     if (alive) {
@@ -1284,6 +1287,7 @@ constexpr int kStk2 = 16;
 #ifndef CRT_WF_RING
 #define CRT_WF_RING 32
 #endif
+constexpr uint32_t kPatchesRecomputed = CRT_WF_PATCH_RECOMPUTE;
 constexpr uint32_t kRing2 = CRT_WF_RING;        // ready rays per refill of the ring (LDS: 7.3 KB per wave with 32, so that a few waves of the
                                                 // other pipe's traversal launch fit beside sixteen of this one and the two launches' tail and ramp-up overlap)
 
@@ -1332,6 +1336,7 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
     int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
     const size_t ovl = P.overflow_lanes;
     const uint32_t nprim = P.sc.nprim;
+    const bool fetchD = P.sc.npatch > kPatchesRecomputed;
     DevScene S = P.sc;                                         // for the rare patch / sphere tests
     S.prim = prim; S.primD = primD;
 
@@ -1504,7 +1509,11 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                 const uint32_t ps = tk.x;
                 // (the record loads go out first: the ray's values come over under their latency)
                 float4 A = float4{0, 0, 0, 0}, B = A, C = A, D = A;
-                if (lane < T) { A = prim[3 * (size_t)ps + 0]; B = prim[3 * (size_t)ps + 1]; C = prim[3 * (size_t)ps + 2]; D = primD[ps]; }
+                // (The fourth part of a record -- a patch's unit normal and e1.e1 -- is not fetched: behind the category test it was a
+                // dependent round trip in nearly every round of S2, fetched with the other three it was one memory request in four of
+                // EVERY task, triangles included, and the kernel is bound by its requests; the patch task recomputes it below.  S2 +-0,
+                // the 10 M soup +5 %: profiles/r03_ab_patch_recompute.txt.  CRT_WF_PATCH_RECOMPUTE = 0 brings the fetch back.)
+                if (lane < T) { A = prim[3 * (size_t)ps + 0]; B = prim[3 * (size_t)ps + 1]; C = prim[3 * (size_t)ps + 2]; if (fetchD) D = primD[ps]; }
                 // the owners' next node meanwhile (it does not depend on the tests' outcome)
                 bool from_pend = false;
                 if (incl) {
@@ -1528,7 +1537,11 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                     // (D, the patch record's fourth part, was fetched with the other three: 94 % of the rounds on S2 hold a wall patch
                     // among their tasks, and fetched behind the category test it was a dependent round trip in every one of them)
                     if ((f_bits(A.w) & 3u) == 2u) tri_test(A, B, C, ps, to, td, t_excl, t_min, hit_pad, tm, bi, bs);
-                    else hit_test_rec<false>(A, B, C, D, hit_pad, ps, to, td, t_excl, t_min, tm, bi, bs);
+                    else {
+                        // (unit normal and e1.e1 with the operations of the upload, crt_api.cpp: the same bits as the stored part)
+                        if (!fetchD && (f_bits(A.w) & 3u) == 0u) { const f3 nn = normalize(cross(xyz(B), xyz(C))); D = float4{nn.x, nn.y, nn.z, dot(xyz(B), xyz(B))}; }
+                        hit_test_rec<false>(A, B, C, D, hit_pad, ps, to, td, t_excl, t_min, tm, bi, bs);
+                    }
                     if (COUNT && __ballot((f_bits(A.w) & 3u) != 2u) != 0ull) d_scans += 64u;   // (probe: rounds that also run the patch / sphere test; read back / 64)
                     acc = bs != bs0;
                     if (acc) {
