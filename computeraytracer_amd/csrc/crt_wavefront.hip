@@ -51,7 +51,7 @@ namespace crt {
 #define CRT_WF_SPEC 1
 #endif
 #ifndef CRT_WF_PATCH_RECOMPUTE
-#define CRT_WF_PATCH_RECOMPUTE 0xFFFFFFFFu      /* k_wf_trace2 recomputes a patch's fourth record part in scenes with at most this many patches: always */
+#define CRT_WF_PATCH_RECOMPUTE 20      /* k_wf_trace2 recomputes a patch's fourth record part where there are more than 2^this primitives per patch */
 #endif
 #ifndef CRT_WF_SHADE_BLOCK
 #define CRT_WF_SHADE_BLOCK 64
@@ -1287,7 +1287,6 @@ constexpr int kStk2 = 16;
 #ifndef CRT_WF_RING
 #define CRT_WF_RING 32
 #endif
-constexpr uint32_t kPatchesRecomputed = CRT_WF_PATCH_RECOMPUTE;
 constexpr uint32_t kRing2 = CRT_WF_RING;        // ready rays per refill of the ring (LDS: 7.3 KB per wave with 32, so that a few waves of the
                                                 // other pipe's traversal launch fit beside sixteen of this one and the two launches' tail and ramp-up overlap)
 
@@ -1336,7 +1335,7 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
     int *__restrict__ ovf = P.stack_overflow + ((size_t)blockIdx.x * 64 + lane_id());
     const size_t ovl = P.overflow_lanes;
     const uint32_t nprim = P.sc.nprim;
-    const bool fetchD = P.sc.npatch > kPatchesRecomputed;
+    const bool fetchD = ((unsigned long long)P.sc.npatch << CRT_WF_PATCH_RECOMPUTE) > (unsigned long long)nprim;
     DevScene S = P.sc;                                         // for the rare patch / sphere tests
     S.prim = prim; S.primD = primD;
 
@@ -1509,10 +1508,12 @@ __global__ __launch_bounds__(64, CRT_WF_T2_WAVES) void k_wf_trace2(const WfParam
                 const uint32_t ps = tk.x;
                 // (the record loads go out first: the ray's values come over under their latency)
                 float4 A = float4{0, 0, 0, 0}, B = A, C = A, D = A;
-                // (The fourth part of a record -- a patch's unit normal and e1.e1 -- is not fetched: behind the category test it was a
-                // dependent round trip in nearly every round of S2, fetched with the other three it was one memory request in four of
-                // EVERY task, triangles included, and the kernel is bound by its requests; the patch task recomputes it below.  S2 +-0,
-                // the 10 M soup +5 %: profiles/r03_ab_patch_recompute.txt.  CRT_WF_PATCH_RECOMPUTE = 0 brings the fetch back.)
+                // (The fourth part of a record is a patch's: unit normal and e1.e1.  Where a patch task is in nearly every round -- S2's
+                // walls: 94 % -- it is fetched with the other three (behind the category test it was a dependent round trip per
+                // round).  Where patches are a handful among millions of triangles -- the 10 M soup -- that fetch is one memory
+                // request in four of EVERY task for nothing, and the kernel is bound by its requests: left out, the rare patch task
+                // recomputes the part below, +5 % Mrays/s.  Recomputing always is +-0 in time on S2 but +8 % VALU instructions at
+                // 61 instead of 64 % lane utilisation: profiles/r03_ab_patch_recompute.txt.)
                 if (lane < T) { A = prim[3 * (size_t)ps + 0]; B = prim[3 * (size_t)ps + 1]; C = prim[3 * (size_t)ps + 2]; if (fetchD) D = primD[ps]; }
                 // the owners' next node meanwhile (it does not depend on the tests' outcome)
                 bool from_pend = false;
