@@ -150,7 +150,9 @@ int crt_read_rgba8(crt_ctx *ctx, uint8_t *out);
  *                           "frame_ring" = F, set before tracing; k_wf_resolve then stores every sample's frame, bit-identical
  *                           to a synced crt_trace(1) loop).  Waits only for the batch that holds the sample; a display loop
  *                           that requests frames a cohort ahead of the one it shows (host/display_loop.js) sees every frame
- *                           index exactly once while small calls are still merged into cohorts. */
+ *                           index exactly once while small calls are still merged into cohorts.  CRT_EINVAL for a sample that
+ *                           has not been requested, has left the ring, or predates the context's last crt_reset /
+ *                           crt_write_accum / change of "frame_ring" (a restored accumulator brings no frames with it). */
 int crt_read_latest_rgba8(crt_ctx *ctx, uint8_t *out, uint32_t *sample);
 /* Page-lock / release caller memory (hipHostRegister): readbacks into pinned memory run at PCIe speed -- for the frame
  * buffer a display loop reads every frame into.  No context needed; errors are reported through crt_last_error(NULL). */
