@@ -1077,6 +1077,36 @@ def test_native_gather_random_walk_shows_only_complete_frames(orc):
                 r.close()
 
 
+def test_comm_init_failures_leave_nothing_behind():
+    """A failed crt_comm_init (rank taken, world sizes that disagree, a second communicator on one context) leaves neither a
+    member in the id's group nor a communicator on the context: the rank can be taken afterwards, and the group still works."""
+    from computeraytracer_amd import Renderer, cornell
+    from computeraytracer_amd._lib import CrtError
+    ps = cornell(48, 40)
+    cid = Renderer.comm_unique_id(local=True)
+    a, b, c = Renderer(0), Renderer(0), Renderer(0)
+    try:
+        a.comm_init(cid, 0, 2)
+        with pytest.raises(CrtError, match="rank of the id is taken"):
+            b.comm_init(cid, 0, 2)
+        with pytest.raises(CrtError, match="disagree about the world size"):
+            b.comm_init(cid, 1, 3)
+        with pytest.raises(CrtError, match="already has a communicator"):
+            a.comm_init(cid, 1, 2)
+        assert b.comm_info()["world"] == 1                         # (no communicator on b)
+        b.comm_init(cid, 1, 2)                                     # the rank is still free
+        for r in (a, b):
+            r.upload(ps).comm_partition(8).build_accel("bvh2")
+        for r in (a, b):
+            r.frame(2).sync().gather(rgba8=True)
+        c.upload(ps).build_accel("bvh2")
+        c.frame(2)
+        assert np.array_equal(a.read_frame_rgba8(), c.read_rgba8()) and np.array_equal(b.read_frame_rgba8(), c.read_rgba8())
+    finally:
+        for r in (a, b, c):
+            r.close()
+
+
 def test_native_gather_over_rccl_single_rank():
     """The RCCL transport itself on the one GPU the test box has: librccl is loaded on demand, ncclCommInitRank and
     ncclAllGather run with world = 1, and the frame read through the communicator equals the context's own."""
