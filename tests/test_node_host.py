@@ -60,6 +60,17 @@ def test_async_napi_keeps_the_event_loop_free(tmp_path):
 
 
 @pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_async_napi_random_walk(tmp_path):
+    """host/async_walk.js: promises of traceAsync / readSampleRgba8Async / readRgba8Async / syncAsync queued without waiting
+    for the ones before, invalid requests in between (they reject, the queue goes on), blocking calls refused meanwhile;
+    every delivered frame equals the one a synchronous loop shows at that index."""
+    out = subprocess.run([NODE, os.path.join(ROOT, "host", "async_walk.js"), "--size", "96", "--epochs", "6"],
+                         capture_output=True, text=True, check=True)
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["ok"] and info["checked"] > 10 and info["rejected"] > 0, info
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_node_display_loop_shows_every_frame_once(tmp_path):
     """host/display_loop.js: trace(1) per frame, the display lagging by a cohort and a half; every frame index shown once,
     in order, each equal to the frame a synchronous trace(1); sync(); readRgba8() loop shows."""
